@@ -1,0 +1,94 @@
+"""CPU suite: the oracle restatement (oracle/at_oracle.c) against the golden
+vectors produced by the REAL reference (tests/golden, made by
+oracle/make_golden.py), and -- when the compiled reference is present
+(oracle/_ref) -- against the reference itself on fresh random cases."""
+import hashlib
+import random
+
+import pytest
+
+import oracle as O
+from conftest import load_golden
+
+
+def _md5(s):
+    return hashlib.md5(s.encode("latin1")).hexdigest()
+
+
+def _check(case):
+    r = O.align(O.MODE_NAMES[case["mode"]], case["s1"], case["s2"], case["m"], case["u"], case["o"], case["e"],
+                case["j"], case["use_jump"], case["sites"])
+    assert r["rc"] == 0
+    assert r["score"] == case["score"], case["tag"]
+    if case["mode"] == "edit":
+        return
+    if "r1" in case:
+        assert r["r1"] == case["r1"] and r["r2"] == case["r2"], case["tag"]
+    else:
+        assert len(r["r1"]) == case["rlen"]
+        assert _md5(r["r1"]) == case["r1_md5"] and _md5(r["r2"]) == case["r2_md5"], case["tag"]
+
+
+@pytest.mark.parametrize("name", ["known_answers.jsonl", "random_small.jsonl", "random_dna.jsonl"])
+def test_oracle_matches_reference_goldens(name):
+    cases = load_golden(name)
+    assert len(cases) > 30
+    for c in cases:
+        _check(c)
+
+
+def test_survey_known_answers():
+    """SURVEY.md section 4 table, the reference's README examples."""
+    ka = {(c["tag"], c["mode"], c["m"], c["u"], c["o"], c["e"], c["use_jump"]): c for c in load_golden("known_answers.jsonl")}
+    c = ka[("test_local", "local", 2, -2, -5, -2, False)]
+    assert (c["score"], c["r1"], c["r2"]) == (4, "LEA", "MEA")
+    c = ka[("test_global", "global", 1, -1, -4, -1, False)]
+    assert c["score"] == 49 and c["r1"].startswith("PAKK------FQIFWEKQ")
+    c = ka[("test_edit", "edit", 1, 1, 2, -1, False)]
+    assert c["score"] == 683
+    c = ka[("test_edit", "edit", 1, -2, -5, -1, False)]
+    assert c["score"] == 176
+    c = ka[("test_fit -s (README.md:82)", "fit", 2, -2, -5, -1, True)]
+    assert c["score"] == 494 and c["rlen"] == 23762
+
+
+def test_ops_render_roundtrip():
+    """ops (traceback order) + end cell reproduce the gapped strings."""
+    for c in load_golden("random_small.jsonl")[:400]:
+        if c["mode"] == "edit":
+            continue
+        r = O.align(O.MODE_NAMES[c["mode"]], c["s1"], c["s2"], c["m"], c["u"], c["o"], c["e"], c["j"], c["use_jump"], c["sites"])
+        i, j = r["end_i"], r["end_j"]
+        a, b = [], []
+        for op in r["ops"]:
+            if op == O.OP_MID:
+                i -= 1; j -= 1; a.append(c["s1"][i]); b.append(c["s2"][j])
+            elif op == O.OP_LOW:
+                i -= 1; a.append(c["s1"][i]); b.append("-")
+            else:
+                j -= 1; a.append("-"); b.append(c["s2"][j])
+        assert "".join(reversed(a)) == r["r1"] and "".join(reversed(b)) == r["r2"]
+
+
+@pytest.mark.skipif(not O.have_ref(), reason="compiled reference (oracle/_ref) not present")
+def test_oracle_vs_live_reference_random():
+    rng = random.Random(99)
+    n = 0
+    for it in range(1500):
+        mode = it % 5
+        alpha = "ACGT"[: rng.randint(1, 4)]
+        l1, l2 = rng.randint(1, 50), rng.randint(2, 70)
+        if mode == O.FIT:
+            l1 = min(l1, l2)
+        s1 = "".join(rng.choice(alpha) for _ in range(l1))
+        s2 = "".join(rng.choice(alpha) for _ in range(l2))
+        sc = rng.choice([(1, -1, -1, -1), (2, -2, -5, -2), (1, -2, -5, -1), (0, 0, 0, 0), (1, -1, 1, -1)])
+        uj = mode == O.FIT and rng.random() < 0.5
+        sites = [rng.randint(0, l2) for _ in range(3)] if uj else []
+        a = O.align(mode, s1, s2, *sc, -3, uj, sites)
+        if a["rc"] == -2:
+            continue
+        b = O.ref_align(mode, s1, s2, *sc, -3, uj, sites)
+        assert (a["score"], a["r1"], a["r2"]) == (b["score"], b["r1"], b["r2"])
+        n += 1
+    assert n > 1000

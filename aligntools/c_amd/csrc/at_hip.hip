@@ -1,0 +1,454 @@
+/*
+ * at_hip.hip -- the C-ABI shim (include/aligntools_hip.h) over the gfx950
+ * sweep kernel (at_sweep.hip.h).  Host C++ here is plumbing only: argument
+ * checks, packing, the choice of storage class, launches.  There is no CPU
+ * compute path: every DP cell is computed on the GPU or the call fails.
+ */
+#include "at_sweep.hip.h"
+#include "../../../include/aligntools_hip.h"
+
+#include <algorithm>
+#include <cstdarg>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+using at::SweepArgs;
+
+struct at_handle {
+	int device = 0;
+	int ncu = 256;
+	size_t lds_per_cu = 160 * 1024;
+	hipStream_t stream = nullptr;   /* used by the host-buffer entry */
+	/* scoring */
+	int m = 1, u = -2, o = -5, e = -1, j = -10, use_jump = 0;
+	std::vector<int> sites;
+	/* device scratch (grow-only) */
+	uint32_t *d_sitemask = nullptr; size_t sitemask_words = 0; int sitemask_for_l2 = -1; bool sitemask_dirty = true;
+	uint32_t *d_ws = nullptr; size_t ws_bytes = 0;
+	void *d_in = nullptr; size_t in_bytes = 0;
+	void *d_out = nullptr; size_t out_bytes = 0;
+	char err[512] = {0};
+	char cfg[160] = "none";
+};
+
+static char g_err[512] = "no error";
+
+static int fail(at_handle *h, int code, const char *fmt, ...)
+{
+	char buf[512];
+	va_list ap;
+	va_start(ap, fmt);
+	vsnprintf(buf, sizeof buf, fmt, ap);
+	va_end(ap);
+	snprintf(g_err, sizeof g_err, "%s", buf);
+	if (h) snprintf(h->err, sizeof h->err, "%s", buf);
+	return code;
+}
+
+#define HIP_TRY(h, call)                                                                      \
+	do {                                                                                      \
+		hipError_t e_ = (call);                                                               \
+		if (e_ != hipSuccess)                                                                 \
+			return fail((h), AT_ERR_NODEVICE, "%s: %s", #call, hipGetErrorString(e_));        \
+	} while (0)
+
+extern "C" const char *at_last_error(const at_handle *h) { return h ? h->err : g_err; }
+extern "C" const char *at_last_config(const at_handle *h) { return h ? h->cfg : "none"; }
+
+extern "C" int at_init(const int *device_ids, int n_devices, at_handle **out)
+{
+	if (!out) return fail(nullptr, AT_ERR_ARG, "at_init: out is NULL");
+	*out = nullptr;
+	if (n_devices != 1 && !(n_devices == 0 && !device_ids))
+		return fail(nullptr, AT_ERR_ARG, "at_init: one process per GPU -- n_devices must be 1 (got %d)", n_devices);
+	int count = 0;
+	hipError_t e = hipGetDeviceCount(&count);
+	if (e != hipSuccess || count <= 0)
+		return fail(nullptr, AT_ERR_NODEVICE, "at_init: no HIP device (%s); there is no CPU fallback",
+		            e == hipSuccess ? "device count 0" : hipGetErrorString(e));
+	int dev = 0;
+	if (device_ids) dev = device_ids[0];
+	else if (hipGetDevice(&dev) != hipSuccess) dev = 0;
+	if (dev < 0 || dev >= count) return fail(nullptr, AT_ERR_ARG, "at_init: device %d out of range (0..%d)", dev, count - 1);
+	at_handle *h = new at_handle();
+	h->device = dev;
+	HIP_TRY(h, hipSetDevice(dev));
+	hipDeviceProp_t prop;
+	HIP_TRY(h, hipGetDeviceProperties(&prop, dev));
+	h->ncu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+	if (prop.maxSharedMemoryPerMultiProcessor > 0) h->lds_per_cu = prop.maxSharedMemoryPerMultiProcessor;
+	HIP_TRY(h, hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
+	h->err[0] = 0;
+	*out = h;
+	return AT_OK;
+}
+
+extern "C" void at_destroy(at_handle *h)
+{
+	if (!h) return;
+	(void)hipSetDevice(h->device);
+	if (h->d_sitemask) (void)hipFree(h->d_sitemask);
+	if (h->d_ws) (void)hipFree(h->d_ws);
+	if (h->d_in) (void)hipFree(h->d_in);
+	if (h->d_out) (void)hipFree(h->d_out);
+	if (h->stream) (void)hipStreamDestroy(h->stream);
+	delete h;
+}
+
+extern "C" int at_set_scoring(at_handle *h, int m, int u, int o, int e, int j, int use_jump, const int *sites, int nsites)
+{
+	if (!h) return fail(nullptr, AT_ERR_ARG, "at_set_scoring: NULL handle");
+	if (nsites < 0 || (nsites > 0 && !sites)) return fail(h, AT_ERR_ARG, "at_set_scoring: bad site list");
+	h->m = m; h->u = u; h->o = o; h->e = e; h->j = j; h->use_jump = use_jump ? 1 : 0;
+	h->sites.assign(sites, sites + nsites);
+	h->sitemask_dirty = true;
+	return AT_OK;
+}
+
+/* ------------------------------------------------------------------ packing */
+
+static inline int code2(uint8_t c)
+{
+	switch (c) { case 'A': return 0; case 'C': return 1; case 'G': return 2; case 'T': return 3; default: return -1; }
+}
+
+extern "C" int64_t at_pack_words(int64_t npairs, const int32_t *len1, const int32_t *len2, int bits)
+{
+	if (npairs < 0 || !len1 || !len2 || (bits != 2 && bits != 8)) return -1;
+	const int bpw = 32 / bits;
+	int64_t w = 0;
+	for (int64_t k = 0; k < npairs; ++k) {
+		if (len1[k] < 0 || len2[k] < 0) return -1;
+		w += (len1[k] + bpw - 1) / bpw + 1 + (len2[k] + bpw - 1) / bpw + 1;   /* +1: the window reads one word ahead */
+	}
+	return w + 4;
+}
+
+static void pack_one(const uint8_t *s, int len, int bits, uint32_t *dst)
+{
+	const int bpw = 32 / bits;
+	const int nw = (len + bpw - 1) / bpw + 1;
+	for (int w = 0; w < nw; ++w) {
+		uint32_t v = 0;
+		for (int b = 0; b < bpw; ++b) {
+			const int idx = w * bpw + b;
+			if (idx >= len) break;
+			const uint32_t c = bits == 2 ? (uint32_t)code2(s[idx]) : (uint32_t)s[idx];
+			v |= c << (b * bits);
+		}
+		dst[w] = v;
+	}
+}
+
+extern "C" int at_pack_batch(int64_t npairs, const uint8_t *seq_blob,
+                             const int64_t *off1, const int32_t *len1, const int64_t *off2, const int32_t *len2,
+                             int bits, int *bits_out, uint32_t *words_out, int64_t *woff1_out, int64_t *woff2_out)
+{
+	if (npairs < 0 || !seq_blob || !off1 || !len1 || !off2 || !len2 || !woff1_out || !woff2_out)
+		return fail(nullptr, AT_ERR_ARG, "at_pack_batch: NULL argument");
+	if (bits == 0) {
+		bits = 2;
+		for (int64_t k = 0; k < npairs && bits == 2; ++k) {
+			const uint8_t *a = seq_blob + off1[k], *b = seq_blob + off2[k];
+			for (int x = 0; x < len1[k]; ++x) if (code2(a[x]) < 0) { bits = 8; break; }
+			for (int x = 0; x < len2[k] && bits == 2; ++x) if (code2(b[x]) < 0) { bits = 8; break; }
+		}
+	}
+	if (bits != 2 && bits != 8) return fail(nullptr, AT_ERR_ARG, "at_pack_batch: bits must be 0, 2 or 8");
+	if (bits_out) *bits_out = bits;
+	if (!words_out) return AT_OK;   /* query only */
+	const int bpw = 32 / bits;
+	int64_t w = 0;
+	for (int64_t k = 0; k < npairs; ++k) {
+		woff1_out[k] = w;
+		pack_one(seq_blob + off1[k], len1[k], bits, words_out + w);
+		w += (len1[k] + bpw - 1) / bpw + 1;
+		woff2_out[k] = w;
+		pack_one(seq_blob + off2[k], len2[k], bits, words_out + w);
+		w += (len2[k] + bpw - 1) / bpw + 1;
+	}
+	for (int x = 0; x < 4; ++x) words_out[w + x] = 0;
+	return AT_OK;
+}
+
+extern "C" int at_render(const uint8_t *ops, int32_t nops, const uint8_t *s1, int32_t end_i,
+                         const uint8_t *s2, int32_t end_j, char *r1, char *r2)
+{
+	if (nops < 0 || !r1 || !r2 || (nops > 0 && (!ops || !s1 || !s2))) return AT_ERR_ARG;
+	int i = end_i, j = end_j;
+	for (int k = 0; k < nops; ++k) {
+		const int pos = nops - 1 - k;
+		switch (ops[k]) {
+		case AT_OP_MID: if (i <= 0 || j <= 0) return AT_ERR_ARG; r1[pos] = (char)s1[--i]; r2[pos] = (char)s2[--j]; break;
+		case AT_OP_LOW: if (i <= 0) return AT_ERR_ARG; r1[pos] = (char)s1[--i]; r2[pos] = '-'; break;
+		case AT_OP_UPP:
+		case AT_OP_JUMP: if (j <= 0) return AT_ERR_ARG; r1[pos] = '-'; r2[pos] = (char)s2[--j]; break;
+		default: return AT_ERR_ARG;
+		}
+	}
+	r1[nops] = 0; r2[nops] = 0;
+	return AT_OK;
+}
+
+/* ----------------------------------------------------------------- dispatch */
+
+typedef void (*sweep_fn)(const SweepArgs);
+
+template <int MODE, int BITS>
+static sweep_fn pick2(bool small, bool tb)
+{
+	if (small) return tb ? at::at_sweep<MODE, BITS, true, true> : at::at_sweep<MODE, BITS, true, false>;
+	return tb ? at::at_sweep<MODE, BITS, false, true> : at::at_sweep<MODE, BITS, false, false>;
+}
+template <int BITS>
+static sweep_fn pick_edit(bool small)
+{
+	return small ? at::at_sweep<at::K_EDIT, BITS, true, false> : at::at_sweep<at::K_EDIT, BITS, false, false>;
+}
+template <int BITS>
+static sweep_fn pick1(int kmode, bool small, bool tb)
+{
+	switch (kmode) {
+	case at::K_GLOBAL: return pick2<at::K_GLOBAL, BITS>(small, tb);
+	case at::K_LOCAL: return pick2<at::K_LOCAL, BITS>(small, tb);
+	case at::K_FIT: return pick2<at::K_FIT, BITS>(small, tb);
+	case at::K_FITJ: return pick2<at::K_FITJ, BITS>(small, tb);
+	case at::K_OVERLAP: return pick2<at::K_OVERLAP, BITS>(small, tb);
+	default: return pick_edit<BITS>(small);
+	}
+}
+
+struct Layout {
+	int off_bound, off_ptr;
+	long long words;
+};
+
+static Layout layout_for(int kmode, int bits, bool tb, int max_l1, int max_l2)
+{
+	const int bpw = 32 / bits;
+	const int tbk = (max_l2 + 63 + at::kBlk - 1) / at::kBlk;
+	const int rpb = kmode == at::K_FITJ ? 2 : 1;
+	const long long nstrips = (max_l1 + 63) / 64;
+	long long nref = (at::kPad + (long long)tbk * at::kBlk + 16) / bpw + 3;
+	nref = (nref + 1) & ~1LL;
+	const long long nbound = 2LL * (max_l2 + 2);
+	const long long nptr = (tb && kmode != at::K_EDIT) ? nstrips * tbk * rpb * 64 : 0;
+	Layout L;
+	L.off_bound = (int)nref;
+	L.off_ptr = (int)(nref + nbound);
+	L.words = nref + nbound + nptr;
+	return L;
+}
+
+static int grow(at_handle *h, void **p, size_t *have, size_t need)
+{
+	if (need <= *have) return AT_OK;
+	if (*p) { (void)hipFree(*p); *p = nullptr; *have = 0; }
+	need = need + need / 8 + 4096;
+	hipError_t e = hipMalloc(p, need);
+	if (e != hipSuccess) return fail(h, AT_ERR_NOMEM, "hipMalloc(%zu): %s", need, hipGetErrorString(e));
+	*have = need;
+	return AT_OK;
+}
+
+static int ensure_sitemask(at_handle *h, int max_l2, hipStream_t stream)
+{
+	if (!h->sitemask_dirty && h->sitemask_for_l2 >= max_l2) return AT_OK;
+	const size_t nbits = (size_t)max_l2 + 64 + 64 + 128;
+	const size_t nw = (nbits + 31) / 32 + 2;
+	std::vector<uint32_t> m(nw, 0xffffffffu);
+	/* column j (1-based) may open the jump state iff (j-1) is NOT a listed site
+	 * -- the reference's inverted test, alignment.h:659 / SURVEY.md 0.4 */
+	for (int sidx : h->sites) {
+		const long long j = (long long)sidx + 1;
+		if (j < 0 || (size_t)(j + 64) >= nbits) continue;
+		m[(size_t)(j + 64) >> 5] &= ~(1u << ((j + 64) & 31));
+	}
+	void *p = h->d_sitemask; size_t have = h->sitemask_words * 4;
+	int rc = grow(h, &p, &have, nw * 4);
+	h->d_sitemask = (uint32_t *)p; h->sitemask_words = have / 4;
+	if (rc) return rc;
+	HIP_TRY(h, hipMemcpyAsync(h->d_sitemask, m.data(), nw * 4, hipMemcpyHostToDevice, stream));
+	HIP_TRY(h, hipStreamSynchronize(stream));   /* m is a temporary */
+	h->sitemask_dirty = false;
+	h->sitemask_for_l2 = max_l2;
+	return AT_OK;
+}
+
+static long long env_ll(const char *name, long long dflt)
+{
+	const char *v = getenv(name);
+	return v && *v ? atoll(v) : dflt;
+}
+
+extern "C" int at_align_batch_device(at_handle *h, int mode, int64_t npairs,
+                                     const uint32_t *d_seq, int bits,
+                                     const int64_t *d_woff1, const int32_t *d_len1,
+                                     const int64_t *d_woff2, const int32_t *d_len2,
+                                     int32_t max_len1, int32_t max_len2, int want_traceback,
+                                     int32_t *d_score, int32_t *d_end_i, int32_t *d_end_j, int32_t *d_state,
+                                     uint8_t *d_ops, const int64_t *d_ops_off, int32_t *d_nops, void *stream_)
+{
+	if (!h) return fail(nullptr, AT_ERR_ARG, "at_align_batch_device: NULL handle");
+	if (mode < AT_MODE_GLOBAL || mode > AT_MODE_EDIT) return fail(h, AT_ERR_ARG, "unknown mode %d", mode);
+	if (npairs < 0 || max_len1 < 0 || max_len2 < 0) return fail(h, AT_ERR_ARG, "negative size");
+	if (bits != 2 && bits != 8) return fail(h, AT_ERR_ARG, "bits must be 2 or 8");
+	if (npairs == 0) return AT_OK;
+	if (!d_seq || !d_woff1 || !d_len1 || !d_woff2 || !d_len2 || !d_score) return fail(h, AT_ERR_ARG, "NULL device pointer");
+	const bool tb = want_traceback && mode != AT_MODE_EDIT;
+	if (tb && (!d_ops || !d_ops_off || !d_nops)) return fail(h, AT_ERR_ARG, "traceback wanted but ops buffers are NULL");
+	hipStream_t stream = (hipStream_t)stream_;
+	HIP_TRY(h, hipSetDevice(h->device));
+
+	/* exact-int32 range: real scores stay within 2^24, sentinel at -2^26 (at_sweep.hip.h) */
+	long long maxabs = 0;
+	for (int v : {h->m, h->u, h->o, h->e, h->j}) maxabs = std::max<long long>(maxabs, std::llabs((long long)v));
+	maxabs = std::max<long long>(maxabs, 1);
+	if (maxabs * ((long long)max_len1 + max_len2 + 2) >= (1LL << 24))
+		return fail(h, AT_ERR_RANGE, "scores may exceed the exact range: max|param|=%lld, l1+l2=%lld", maxabs,
+		            (long long)max_len1 + max_len2);
+
+	const int kmode = mode == AT_MODE_GLOBAL ? at::K_GLOBAL : mode == AT_MODE_LOCAL ? at::K_LOCAL
+	                : mode == AT_MODE_FIT ? (h->use_jump ? at::K_FITJ : at::K_FIT)
+	                : mode == AT_MODE_OVERLAP ? at::K_OVERLAP : at::K_EDIT;
+	const Layout L = layout_for(kmode, bits, tb, max_len1, max_len2);
+	if (L.words >= (1LL << 30)) return fail(h, AT_ERR_RANGE, "pair too large: %lld workspace words", L.words);
+
+	const long long small_limit = env_ll("AT_SMALL_LDS_LIMIT", 40 * 1024);
+	const size_t lds_bytes = (size_t)L.words * 4;
+	const bool small = (long long)lds_bytes <= small_limit && !env_ll("AT_FORCE_LARGE", 0);
+
+	SweepArgs a;
+	memset(&a, 0, sizeof a);
+	a.npairs = npairs;
+	a.seq = d_seq;
+	a.woff1 = (const long long *)d_woff1; a.len1 = d_len1;
+	a.woff2 = (const long long *)d_woff2; a.len2 = d_len2;
+	a.m16 = h->m * 16; a.u16 = h->u * 16; a.o16 = h->o * 16; a.e16 = h->e * 16; a.g16 = h->j * 16;
+	a.u_raw = h->u;
+	a.score = d_score; a.end_i = d_end_i; a.end_j = d_end_j; a.state = d_state;
+	a.ops = d_ops; a.ops_off = (const long long *)d_ops_off; a.nops = d_nops;
+	a.off_bound = L.off_bound; a.off_ptr = L.off_ptr;
+	if (kmode == at::K_FITJ) {
+		int rc = ensure_sitemask(h, max_len2, stream);
+		if (rc) return rc;
+		a.sitemask = h->d_sitemask;
+	}
+
+	long long grid;
+	size_t dyn_lds = 0;
+	if (small) {
+		long long per_cu = (long long)((h->lds_per_cu - 1024) / std::max<size_t>(lds_bytes, 512));
+		per_cu = std::max(1LL, std::min(per_cu, env_ll("AT_WAVES_PER_CU", 16)));
+		grid = std::min<long long>(npairs, per_cu * h->ncu);
+		dyn_lds = lds_bytes;
+		snprintf(h->cfg, sizeof h->cfg, "small(lds) bits=%d lds=%zuB waves/cu=%lld grid=%lld", bits, lds_bytes, per_cu, grid);
+	} else {
+		long long per_cu = env_ll("AT_WAVES_PER_CU", 16);
+		grid = std::min<long long>(npairs, per_cu * h->ncu);
+		const long long cap = env_ll("AT_WS_CAP_MB", 16384) << 20;
+		const long long slot_bytes = ((L.words + 63) & ~63LL) * 4;
+		if (slot_bytes > cap) return fail(h, AT_ERR_NOMEM, "one pair needs %lld workspace bytes (cap %lld)", slot_bytes, cap);
+		grid = std::max(1LL, std::min(grid, cap / slot_bytes));
+		void *p = h->d_ws; size_t have = h->ws_bytes;
+		int rc = grow(h, &p, &have, (size_t)(grid * slot_bytes));
+		h->d_ws = (uint32_t *)p; h->ws_bytes = have;
+		if (rc) return rc;
+		a.ws = h->d_ws;
+		a.ws_slot_words = slot_bytes / 4;
+		snprintf(h->cfg, sizeof h->cfg, "large(hbm) bits=%d slot=%lldB grid=%lld", bits, slot_bytes, grid);
+	}
+	sweep_fn fn = bits == 2 ? pick1<2>(kmode, small, tb) : pick1<8>(kmode, small, tb);
+	if (dyn_lds > 48 * 1024)
+		HIP_TRY(h, hipFuncSetAttribute((const void *)fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn_lds));
+	hipLaunchKernelGGL(fn, dim3((unsigned)grid), dim3(64), dyn_lds, stream, a);
+	HIP_TRY(h, hipGetLastError());
+	return AT_OK;
+}
+
+extern "C" int at_align_batch(at_handle *h, int mode, int64_t npairs, const uint8_t *seq_blob,
+                              const int64_t *off1, const int32_t *len1, const int64_t *off2, const int32_t *len2,
+                              int want_traceback,
+                              int32_t *out_score, int32_t *out_end_i, int32_t *out_end_j, int32_t *out_state,
+                              uint8_t *out_ops, const int64_t *ops_off, int32_t *out_nops)
+{
+	if (!h) return fail(nullptr, AT_ERR_ARG, "at_align_batch: NULL handle");
+	if (mode < AT_MODE_GLOBAL || mode > AT_MODE_EDIT) return fail(h, AT_ERR_ARG, "unknown mode %d", mode);
+	if (npairs < 0) return fail(h, AT_ERR_ARG, "negative npairs");
+	if (npairs == 0) return AT_OK;
+	if (!seq_blob || !off1 || !len1 || !off2 || !len2 || !out_score) return fail(h, AT_ERR_ARG, "NULL argument");
+	const bool tb = want_traceback && mode != AT_MODE_EDIT;
+	if (tb && (!out_ops || !ops_off || !out_nops)) return fail(h, AT_ERR_ARG, "traceback wanted but ops buffers are NULL");
+
+	int max1 = 0, max2 = 0;
+	int64_t ops_total = 0;
+	for (int64_t k = 0; k < npairs; ++k) {
+		if (len1[k] < 0 || len2[k] < 0) return fail(h, AT_ERR_ARG, "pair %lld: negative length", (long long)k);
+		/* the domain on which the reference is defined (last paragraph) */
+		if (mode == AT_MODE_FIT && len1[k] > len2[k])
+			return fail(h, AT_ERR_FIT_ORDER, "first sequence must be shorter than the second");
+		if (mode == AT_MODE_LOCAL && (len1[k] < 1 || len2[k] < 1)) return fail(h, AT_ERR_DOMAIN, "pair %lld: local needs non-empty sequences", (long long)k);
+		if (mode == AT_MODE_FIT && len1[k] < 1) return fail(h, AT_ERR_DOMAIN, "pair %lld: fit needs a non-empty read", (long long)k);
+		if (mode == AT_MODE_OVERLAP && len2[k] < 1) return fail(h, AT_ERR_DOMAIN, "pair %lld: overlap needs a non-empty second sequence", (long long)k);
+		max1 = std::max(max1, len1[k]); max2 = std::max(max2, len2[k]);
+		if (tb) ops_total = std::max<int64_t>(ops_total, ops_off[k] + len1[k] + len2[k]);
+	}
+	HIP_TRY(h, hipSetDevice(h->device));
+
+	int bits = 0;
+	int rc = at_pack_batch(npairs, seq_blob, off1, len1, off2, len2, 0, &bits, nullptr, (int64_t *)off1 /*unused*/, (int64_t *)off2);
+	if (rc) return rc;
+	const int64_t nwords = at_pack_words(npairs, len1, len2, bits);
+	std::vector<uint32_t> words((size_t)nwords);
+	std::vector<int64_t> woff1((size_t)npairs), woff2((size_t)npairs);
+	rc = at_pack_batch(npairs, seq_blob, off1, len1, off2, len2, bits, nullptr, words.data(), woff1.data(), woff2.data());
+	if (rc) return rc;
+
+	/* device input block: words | woff1 | woff2 | len1 | len2 | ops_off */
+	auto al = [](size_t x) { return (x + 255) & ~(size_t)255; };
+	const size_t b_words = al((size_t)nwords * 4), b_off = al((size_t)npairs * 8), b_len = al((size_t)npairs * 4);
+	const size_t in_need = b_words + 3 * b_off + 2 * b_len;
+	rc = grow(h, &h->d_in, &h->in_bytes, in_need);
+	if (rc) return rc;
+	char *din = (char *)h->d_in;
+	uint32_t *d_words = (uint32_t *)din;
+	int64_t *d_woff1 = (int64_t *)(din + b_words), *d_woff2 = (int64_t *)(din + b_words + b_off);
+	int64_t *d_opsoff = (int64_t *)(din + b_words + 2 * b_off);
+	int32_t *d_len1 = (int32_t *)(din + b_words + 3 * b_off), *d_len2 = (int32_t *)(din + b_words + 3 * b_off + b_len);
+	/* device output block: score | end_i | end_j | state | nops | ops */
+	const size_t out_need = 5 * b_len + al((size_t)ops_total + 64);
+	rc = grow(h, &h->d_out, &h->out_bytes, out_need);
+	if (rc) return rc;
+	char *dout = (char *)h->d_out;
+	int32_t *d_score = (int32_t *)dout, *d_ei = (int32_t *)(dout + b_len), *d_ej = (int32_t *)(dout + 2 * b_len);
+	int32_t *d_st = (int32_t *)(dout + 3 * b_len), *d_nops = (int32_t *)(dout + 4 * b_len);
+	uint8_t *d_ops = (uint8_t *)(dout + 5 * b_len);
+
+	hipStream_t s = h->stream;
+	HIP_TRY(h, hipMemcpyAsync(d_words, words.data(), (size_t)nwords * 4, hipMemcpyHostToDevice, s));
+	HIP_TRY(h, hipMemcpyAsync(d_woff1, woff1.data(), (size_t)npairs * 8, hipMemcpyHostToDevice, s));
+	HIP_TRY(h, hipMemcpyAsync(d_woff2, woff2.data(), (size_t)npairs * 8, hipMemcpyHostToDevice, s));
+	HIP_TRY(h, hipMemcpyAsync(d_len1, len1, (size_t)npairs * 4, hipMemcpyHostToDevice, s));
+	HIP_TRY(h, hipMemcpyAsync(d_len2, len2, (size_t)npairs * 4, hipMemcpyHostToDevice, s));
+	if (tb) HIP_TRY(h, hipMemcpyAsync(d_opsoff, ops_off, (size_t)npairs * 8, hipMemcpyHostToDevice, s));
+	rc = at_align_batch_device(h, mode, npairs, d_words, bits, d_woff1, d_len1, d_woff2, d_len2, max1, max2, tb ? 1 : 0,
+	                           d_score, d_ei, d_ej, d_st, tb ? d_ops : nullptr, tb ? d_opsoff : nullptr, tb ? d_nops : nullptr, s);
+	if (rc) return rc;
+	HIP_TRY(h, hipMemcpyAsync(out_score, d_score, (size_t)npairs * 4, hipMemcpyDeviceToHost, s));
+	if (out_end_i) HIP_TRY(h, hipMemcpyAsync(out_end_i, d_ei, (size_t)npairs * 4, hipMemcpyDeviceToHost, s));
+	if (out_end_j) HIP_TRY(h, hipMemcpyAsync(out_end_j, d_ej, (size_t)npairs * 4, hipMemcpyDeviceToHost, s));
+	if (out_state) HIP_TRY(h, hipMemcpyAsync(out_state, d_st, (size_t)npairs * 4, hipMemcpyDeviceToHost, s));
+	if (tb) {
+		HIP_TRY(h, hipMemcpyAsync(out_nops, d_nops, (size_t)npairs * 4, hipMemcpyDeviceToHost, s));
+		HIP_TRY(h, hipMemcpyAsync(out_ops, d_ops, (size_t)ops_total, hipMemcpyDeviceToHost, s));
+	}
+	HIP_TRY(h, hipStreamSynchronize(s));
+	for (int64_t k = 0; k < npairs; ++k) {
+		if (out_score[k] == INT32_MIN || (tb && out_nops[k] < 0))
+			return fail(h, AT_ERR_DOMAIN, "pair %lld: input outside the domain on which the reference is defined", (long long)k);
+	}
+	return AT_OK;
+}

@@ -1,0 +1,137 @@
+/*
+ * aligntools_hip.h -- C ABI of the MI355X (gfx950) alignment shim.
+ *
+ * This is the drop-in boundary for the dynamic-programming hot path of
+ * r3fang/alignTools: the O(l1*l2) matrix fill + pointer traceback of
+ *
+ *     align_gla               reference src/alignment.h:417-473 (+ :372-412)
+ *     align_local_affine      reference src/alignment.h:805-847 (+ :766-800)
+ *     align_fit_affine_jump   reference src/alignment.h:596-694 (+ :558-592)
+ *     align_overlap           reference src/alignment.h:926-964 (+ :896-922)
+ *     edit_dist               reference src/alignment.h:291-315
+ *
+ * The reference has no FFI of its own (it is one C translation unit); these
+ * entry points are what its five main_* drivers (alignment.h:318,476,698,851,
+ * 967) call instead of the align_*() functions -- see include/aligntools.h for
+ * the reference-shaped single-pair wrappers and INTEGRATION.md for the patch.
+ *
+ * Plain C: pointers and sizes only, int return (0 = AT_OK, negative = error,
+ * text via at_last_error), caller-owned buffers, one handle per thread.
+ * There is NO CPU fallback: without a HIP device at_init fails.
+ */
+#ifndef ALIGNTOOLS_HIP_H
+#define ALIGNTOOLS_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* sub-commands (reference src/main.c:39-43) */
+enum { AT_MODE_GLOBAL = 0, AT_MODE_LOCAL = 1, AT_MODE_FIT = 2, AT_MODE_OVERLAP = 3, AT_MODE_EDIT = 4 };
+
+/* traceback ops, emitted END -> START (the order the reference's trace_back_*
+ * loops produce characters before strrev, alignment.h:372-412) */
+enum { AT_OP_MID = 0,   /* (s1[i-1], s2[j-1]); i--, j--                    */
+       AT_OP_LOW = 1,   /* (s1[i-1], '-');     i--                          */
+       AT_OP_UPP = 2,   /* ('-', s2[j-1]);     j--                          */
+       AT_OP_JUMP = 3   /* ('-', s2[j-1]);     j--   fit jump state         */ };
+
+/* state the traceback starts in (reference LOW/MID/UPP, alignment.h:31-33) */
+enum { AT_ST_LOW = 1, AT_ST_MID = 2, AT_ST_UPP = 3 };
+
+enum { AT_OK = 0,
+       AT_ERR_ARG = -1,        /* NULL / negative size / unknown mode                  */
+       AT_ERR_NODEVICE = -2,   /* no HIP device / HIP runtime error                    */
+       AT_ERR_RANGE = -3,      /* |score| could leave the exact int32 range            */
+       AT_ERR_DOMAIN = -4,     /* input outside the domain the reference defines       */
+       AT_ERR_FIT_ORDER = -5,  /* fit: first sequence longer than the second (:599)    */
+       AT_ERR_NOMEM = -6 };
+
+typedef struct at_handle at_handle;
+
+/* Bind to one GPU.  One process (or thread) per GPU: n_devices must be 1.
+ * device_ids == NULL selects the current device. */
+int at_init(const int *device_ids, int n_devices, at_handle **out);
+void at_destroy(at_handle *h);
+const char *at_last_error(const at_handle *h);
+
+/* Scoring block = the reference's opt_t (alignment.h:57-65, defaults :102-114:
+ * o=-5 e=-1 m=1 u=-2 j=-10 s=false).  `sites` are 0-based positions on s2 as
+ * parsed from the 2nd record's FASTA comment (alignment.h:243-256); only used
+ * by AT_MODE_FIT with use_jump.  The reference's inverted junction predicate
+ * (alignment.h:659) is reproduced: M->J may open at column j
+ * iff (j-1) is NOT listed. */
+int at_set_scoring(at_handle *h, int m, int u, int o, int e, int j,
+                   int use_jump, const int *sites, int nsites);
+
+/*
+ * Align a batch of independent pairs held in HOST memory.
+ *   seq_blob          raw sequence bytes (any alphabet; compared by byte
+ *                     equality like alignment.h:449).  All-ACGT batches take
+ *                     the 2-bit packed path, others the 8-bit path, both on GPU.
+ *   off1/len1, off2/len2   per pair: byte offset and length of s1 and s2
+ *   want_traceback    0 = scores and end cells only
+ *   out_score[n]      reference return value (align_*: the double, always an
+ *                     integer; edit: the distance)
+ *   out_end_i/j[n]    cell the traceback starts from (1-based DP coordinates)
+ *   out_state[n]      AT_ST_* start state
+ *   out_ops, ops_off[n], out_nops[n]
+ *                     ops of pair k are written to out_ops[ops_off[k] ..] (at
+ *                     most len1+len2 of them), count in out_nops[k]
+ * Any out_* may be NULL if not wanted (out_ops/ops_off/out_nops together).
+ */
+int at_align_batch(at_handle *h, int mode, int64_t npairs,
+                   const uint8_t *seq_blob,
+                   const int64_t *off1, const int32_t *len1,
+                   const int64_t *off2, const int32_t *len2,
+                   int want_traceback,
+                   int32_t *out_score, int32_t *out_end_i, int32_t *out_end_j, int32_t *out_state,
+                   uint8_t *out_ops, const int64_t *ops_off, int32_t *out_nops);
+
+/*
+ * Same, with every buffer already resident in DEVICE memory (HBM) and the
+ * sequences already packed (at_pack_batch): the entry the batch driver and
+ * bench.py use.  Asynchronous on `stream` (a hipStream_t, NULL = default).
+ *   d_seq      packed words; bits = 2 (A,C,G,T -> 0..3, 16 bases per int32,
+ *              base k of a sequence in bits [2k%32, 2k%32+1] of word k/16) or
+ *              bits = 8 (4 bytes per int32, little endian)
+ *   d_woff1/2  per pair WORD offset of s1 / s2 in d_seq
+ *   max_len1/2 upper bounds of len1/len2 over the batch (sizes LDS / workspace)
+ */
+int at_align_batch_device(at_handle *h, int mode, int64_t npairs,
+                          const uint32_t *d_seq, int bits,
+                          const int64_t *d_woff1, const int32_t *d_len1,
+                          const int64_t *d_woff2, const int32_t *d_len2,
+                          int32_t max_len1, int32_t max_len2,
+                          int want_traceback,
+                          int32_t *d_score, int32_t *d_end_i, int32_t *d_end_j, int32_t *d_state,
+                          uint8_t *d_ops, const int64_t *d_ops_off, int32_t *d_nops,
+                          void *stream);
+
+/* Host helper: pack `npairs` pairs of raw bytes into the word layout above.
+ * bits = 0 picks 2 when every byte is one of ACGT, else 8; the choice is
+ * returned in *bits_out.  words_out must hold at_pack_words(...) int32s. */
+int64_t at_pack_words(int64_t npairs, const int32_t *len1, const int32_t *len2, int bits);
+int at_pack_batch(int64_t npairs, const uint8_t *seq_blob,
+                  const int64_t *off1, const int32_t *len1,
+                  const int64_t *off2, const int32_t *len2,
+                  int bits, int *bits_out,
+                  uint32_t *words_out, int64_t *woff1_out, int64_t *woff2_out);
+
+/* Host helper: ops (END -> START) + end cell -> the reference's two gapped
+ * strings (what trace_back_* + strrev produce).  r1/r2 need nops+1 bytes. */
+int at_render(const uint8_t *ops, int32_t nops,
+              const uint8_t *s1, int32_t end_i, const uint8_t *s2, int32_t end_j,
+              char *r1, char *r2);
+
+/* Introspection for benchmarks / tests: name of the kernel configuration the
+ * last batch ran with ("small"/"large", bits, waves), never NULL. */
+const char *at_last_config(const at_handle *h);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* ALIGNTOOLS_HIP_H */

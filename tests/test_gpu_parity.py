@@ -1,0 +1,98 @@
+"""GPU suite (-m gpu): the HIP path, called through the C ABI, against
+  (1) the golden vectors the real reference produced (tests/golden), bit-exact
+      score and both gapped strings, and
+  (2) the oracle restatement on fresh seeded inputs (ops, end cell, start state).
+"""
+import hashlib
+import random
+from collections import defaultdict
+
+import numpy as np
+import pytest
+
+import oracle as O
+from conftest import load_golden
+
+pytestmark = pytest.mark.gpu
+
+
+def _md5(s):
+    return hashlib.md5(s.encode("latin1")).hexdigest()
+
+
+@pytest.fixture(scope="module")
+def al():
+    import aligntools.c_amd as A
+    a = A.Aligner()
+    yield a
+    a.close()
+
+
+def _group(cases):
+    g = defaultdict(list)
+    for c in cases:
+        g[(c["mode"], c["m"], c["u"], c["o"], c["e"], c["j"], c["use_jump"], tuple(c["sites"]))].append(c)
+    return g
+
+
+def _run_group(al, key, cases):
+    mode, m, u, o, e, j, uj, sites = key
+    al.set_scoring(m, u, o, e, j, uj, list(sites))
+    res = al.align_batch(mode, [(c["s1"], c["s2"]) for c in cases])
+    for k, c in enumerate(cases):
+        assert int(res["score"][k]) == c["score"], (key, c["tag"], k, c["s1"][:40], c["s2"][:40])
+        if mode == "edit":
+            continue
+        if "r1" in c:
+            assert res["r1"][k] == c["r1"] and res["r2"][k] == c["r2"], (key, c["tag"], k)
+        else:
+            assert len(res["r1"][k]) == c["rlen"]
+            assert _md5(res["r1"][k]) == c["r1_md5"] and _md5(res["r2"][k]) == c["r2_md5"], (key, c["tag"])
+
+
+@pytest.mark.parametrize("name", ["random_small.jsonl", "random_dna.jsonl", "known_answers.jsonl"])
+def test_hip_matches_reference_goldens(al, name):
+    groups = _group(load_golden(name))
+    for key, cases in groups.items():
+        _run_group(al, key, cases)
+
+
+def test_hip_matches_oracle_ops_and_end_cells(al):
+    """ops (END->START), end cell and start state equal the restatement's."""
+    rng = random.Random(4242)
+    for mode in ("global", "local", "fit", "overlap"):
+        for sc in ((2, -2, -5, -2), (1, -1, -1, -1), (1, -2, -5, -1)):
+            pairs = []
+            for _ in range(120):
+                l1, l2 = rng.randint(1, 200), rng.randint(2, 260)
+                if mode == "fit":
+                    l1 = min(l1, l2)
+                s1 = "".join(rng.choice("ACGT") for _ in range(l1))
+                if rng.random() < 0.5:
+                    s2 = "".join(rng.choice("ACGT") for _ in range(l2))
+                else:
+                    s2 = ("".join(rng.choice("ACGT") for _ in range(rng.randint(0, 30))) + s1[: rng.randint(1, l1)] +
+                          "".join(rng.choice("ACGT") for _ in range(rng.randint(1, 30))))
+                    if mode == "fit" and len(s2) < len(s1):
+                        s2 = s2 + s1
+                pairs.append((s1, s2))
+            uj = mode == "fit" and sc[0] == 2
+            sites = [50, 100, 101, 150] if uj else []
+            al.set_scoring(*sc, -7, uj, sites)
+            res = al.align_batch(mode, pairs)
+            for k, (s1, s2) in enumerate(pairs):
+                r = O.align(O.MODE_NAMES[mode], s1, s2, *sc, -7, uj, sites)
+                assert r["rc"] == 0
+                assert int(res["score"][k]) == r["score"]
+                assert (int(res["end_i"][k]), int(res["end_j"][k]), int(res["state"][k])) == (r["end_i"], r["end_j"], r["state"])
+                assert res["ops"][k] == r["ops"]
+
+
+def test_reference_named_surface(al):
+    import aligntools.c_amd as A
+    opt = A.opt_t(m=2, u=-2, o=-5, e=-2)
+    assert A.align_local_affine("PLEASANTLY", "MEANLY", opt) == (4.0, "LEA", "MEA")
+    assert A.edit_dist("kitten", "sitting", A.opt_t(u=1)) == 3
+    with pytest.raises(A.AlignToolsError) as ei:
+        A.align_fit_affine_jump("ACGTACGT", "ACG")
+    assert "first sequence must be shorter" in str(ei.value)

@@ -64,7 +64,7 @@ def load_library():
                                    C.c_void_p, C.c_void_p, C.c_void_p]
     lib.at_align_batch_device.restype = C.c_int
     lib.at_align_batch_device.argtypes = [C.c_void_p, C.c_int, C.c_int64, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p,
-                                          C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int,
+                                          C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int, C.c_int,
                                           C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                           C.c_void_p, C.c_void_p]
     lib.at_pack_words.restype = C.c_int64
@@ -214,9 +214,10 @@ class Aligner:
 
     # raw device-pointer entry (bench.py): all arguments are integer device addresses
     def align_batch_device(self, mode, npairs, d_seq, bits, d_woff1, d_len1, d_woff2, d_len2, max_len1, max_len2,
-                           want_traceback, d_score, d_end_i, d_end_j, d_state, d_ops, d_ops_off, d_nops, stream=0):
+                           uniform_shape, want_traceback, d_score, d_end_i, d_end_j, d_state, d_ops, d_ops_off, d_nops, stream=0):
         self._check(self._lib.at_align_batch_device(self._h, mode, npairs, d_seq, bits, d_woff1, d_len1, d_woff2, d_len2,
-                                                    max_len1, max_len2, 1 if want_traceback else 0, d_score, d_end_i,
+                                                    max_len1, max_len2, 1 if uniform_shape else 0,
+                                                    1 if want_traceback else 0, d_score, d_end_i,
                                                     d_end_j, d_state, d_ops, d_ops_off, d_nops, stream))
 
 

@@ -15,7 +15,7 @@ def _newer(target, sources):
 
 def build(force=False, verbose=False):
     """Compile every HIP source for gfx950 (hipcc cross-compiles without a GPU)."""
-    r = subprocess.run(["make", "-C", HERE] + (["-B"] if force else []), capture_output=True, text=True)
+    r = subprocess.run(["make", "-j8", "-C", HERE] + (["-B"] if force else []), capture_output=True, text=True)
     if verbose or r.returncode:
         print(r.stdout[-4000:])
         print(r.stderr[-4000:])

@@ -4,7 +4,7 @@
  * checks, packing, the choice of storage class, launches.  There is no CPU
  * compute path: every DP cell is computed on the GPU or the call fails.
  */
-#include "at_sweep.hip.h"
+#include "at_launch.h"
 #include "../../../include/aligntools_hip.h"
 
 #include <algorithm>
@@ -16,6 +16,7 @@
 #include <vector>
 
 using at::SweepArgs;
+using at::Sweep16Args;
 
 struct at_handle {
 	int device = 0;
@@ -195,52 +196,79 @@ extern "C" int at_render(const uint8_t *ops, int32_t nops, const uint8_t *s1, in
 
 /* ----------------------------------------------------------------- dispatch */
 
-typedef void (*sweep_fn)(const SweepArgs);
-
-template <int MODE, int BITS>
-static sweep_fn pick2(bool small, bool tb)
-{
-	if (small) return tb ? at::at_sweep<MODE, BITS, true, true> : at::at_sweep<MODE, BITS, true, false>;
-	return tb ? at::at_sweep<MODE, BITS, false, true> : at::at_sweep<MODE, BITS, false, false>;
-}
-template <int BITS>
-static sweep_fn pick_edit(bool small)
-{
-	return small ? at::at_sweep<at::K_EDIT, BITS, true, false> : at::at_sweep<at::K_EDIT, BITS, false, false>;
-}
-template <int BITS>
-static sweep_fn pick1(int kmode, bool small, bool tb)
-{
-	switch (kmode) {
-	case at::K_GLOBAL: return pick2<at::K_GLOBAL, BITS>(small, tb);
-	case at::K_LOCAL: return pick2<at::K_LOCAL, BITS>(small, tb);
-	case at::K_FIT: return pick2<at::K_FIT, BITS>(small, tb);
-	case at::K_FITJ: return pick2<at::K_FITJ, BITS>(small, tb);
-	case at::K_OVERLAP: return pick2<at::K_OVERLAP, BITS>(small, tb);
-	default: return pick_edit<BITS>(small);
-	}
-}
-
 struct Layout {
-	int off_bound, off_ptr;
+	int off_bound, off_ptr, k, ptr_lanes;
 	long long words;
 };
+
+/* rows per lane: enough to hold max_l1 in one strip of 64 lanes, at most 4 */
+static int rows_per_lane(int max_l1)
+{
+	const long long forced = getenv("AT_ROWS_PER_LANE") ? atoll(getenv("AT_ROWS_PER_LANE")) : 0;
+	if (forced >= 1 && forced <= 4) return (int)forced;
+	return std::max(1, std::min(4, (max_l1 + 63) / 64));
+}
 
 static Layout layout_for(int kmode, int bits, bool tb, int max_l1, int max_l2)
 {
 	const int bpw = 32 / bits;
 	const int tbk = (max_l2 + 63 + at::kBlk - 1) / at::kBlk;
 	const int rpb = kmode == at::K_FITJ ? 2 : 1;
-	const long long nstrips = (max_l1 + 63) / 64;
+	Layout L;
+	L.k = rows_per_lane(max_l1);
+	L.ptr_lanes = std::max(1, std::min(64, (max_l1 + L.k - 1) / L.k));
+	const long long nstrips = (max_l1 + 64 * L.k - 1) / (64 * L.k);
 	long long nref = (at::kPad + (long long)tbk * at::kBlk + 16) / bpw + 3;
 	nref = (nref + 1) & ~1LL;
 	const long long nbound = 2LL * (max_l2 + 2);
-	const long long nptr = (tb && kmode != at::K_EDIT) ? nstrips * tbk * rpb * 64 : 0;
-	Layout L;
+	const long long nptr = (tb && kmode != at::K_EDIT) ? nstrips * tbk * rpb * L.k * L.ptr_lanes + 64 : 0;
 	L.off_bound = (int)nref;
 	L.off_ptr = (int)(nref + nbound);
 	L.words = nref + nbound + nptr;
 	return L;
+}
+
+
+/* ---- packed int16 path (at_sweep16.hip.h): two same-shape pairs per wave ---- */
+struct Layout16 {
+	int off_refb, off_bound, off_ptr, k, ptr_lanes;
+	long long words;
+};
+
+static Layout16 layout16_for(bool tb, int l1, int l2)
+{
+	const int tbk = (l2 + 63 + at::kBlk - 1) / at::kBlk;
+	Layout16 L;
+	L.k = rows_per_lane(l1);
+	L.ptr_lanes = std::max(1, std::min(64, (l1 + L.k - 1) / L.k));
+	const long long nstrips = (l1 + 64 * L.k - 1) / (64 * L.k);
+	long long nref = (at::kPad + (long long)tbk * at::kBlk) / 4 + 4;
+	nref = (nref + 1) & ~1LL;
+	const long long nbound = 2LL * (l2 + 2);
+	const long long nptr = tb ? nstrips * tbk * 2 * L.k * L.ptr_lanes + 64 : 0;
+	L.off_refb = (int)nref;
+	L.off_bound = (int)(2 * nref);
+	L.off_ptr = (int)(2 * nref + nbound);
+	L.words = 2 * nref + nbound + nptr;
+	return L;
+}
+
+/* Scores of every real (non -inf) cell lie in [-lo, hi]; the packed kernel needs
+ * 16*(lo + hi) plus slack below 2^15 so that the -32768 sentinel, even after the
+ * hi*16 it can gain along a diagonal of matches, stays below every real value. */
+static bool packed_ok(const at_handle *h, int mode, int bits, int l1, int l2, int *thresh16)
+{
+	if (getenv("AT_NO_PACKED") && atoi(getenv("AT_NO_PACKED"))) return false;
+	if (bits != 2 || l1 < 1 || l2 < 1) return false;
+	if (!(mode == AT_MODE_GLOBAL || mode == AT_MODE_LOCAL || (mode == AT_MODE_FIT && !h->use_jump))) return false;
+	if (h->m < 0 || h->u > 0 || h->o > 0 || h->e > 0) return false;
+	const long long A = std::max<long long>(std::max(std::llabs((long long)h->e), std::llabs((long long)h->u)), h->m);
+	const long long lo = 3 * std::llabs((long long)h->o) + A * ((long long)l1 + l2) + 16;
+	const long long hi = (long long)h->m * std::min(l1, l2);
+	const long long slack = std::llabs((long long)h->o) + std::llabs((long long)h->e) + 3;
+	if (16 * (lo + hi + slack) >= 32768) return false;
+	*thresh16 = (int)(-32768 + 16 * (hi + slack));
+	return true;
 }
 
 static int grow(at_handle *h, void **p, size_t *have, size_t need)
@@ -288,7 +316,7 @@ extern "C" int at_align_batch_device(at_handle *h, int mode, int64_t npairs,
                                      const uint32_t *d_seq, int bits,
                                      const int64_t *d_woff1, const int32_t *d_len1,
                                      const int64_t *d_woff2, const int32_t *d_len2,
-                                     int32_t max_len1, int32_t max_len2, int want_traceback,
+                                     int32_t max_len1, int32_t max_len2, int uniform_shape, int want_traceback,
                                      int32_t *d_score, int32_t *d_end_i, int32_t *d_end_j, int32_t *d_state,
                                      uint8_t *d_ops, const int64_t *d_ops_off, int32_t *d_nops, void *stream_)
 {
@@ -314,6 +342,52 @@ extern "C" int at_align_batch_device(at_handle *h, int mode, int64_t npairs,
 	const int kmode = mode == AT_MODE_GLOBAL ? at::K_GLOBAL : mode == AT_MODE_LOCAL ? at::K_LOCAL
 	                : mode == AT_MODE_FIT ? (h->use_jump ? at::K_FITJ : at::K_FIT)
 	                : mode == AT_MODE_OVERLAP ? at::K_OVERLAP : at::K_EDIT;
+
+	/* ---- packed int16 path: uniform shape, scores provably within 16 bits ---- */
+	int thresh16 = 0;
+	if (uniform_shape && packed_ok(h, mode, bits, max_len1, max_len2, &thresh16)) {
+		const Layout16 P = layout16_for(tb, max_len1, max_len2);
+		const size_t lds16 = (size_t)P.words * 4;
+		const long long limit16 = env_ll("AT_SMALL_LDS_LIMIT", 40 * 1024);
+		const bool small16 = (long long)lds16 <= limit16 && !env_ll("AT_FORCE_LARGE", 0);
+		Sweep16Args b;
+		memset(&b, 0, sizeof b);
+		b.npairs = npairs; b.seq = d_seq;
+		b.woff1 = (const long long *)d_woff1; b.woff2 = (const long long *)d_woff2;
+		b.l1 = max_len1; b.l2 = max_len2;
+		b.m16 = h->m * 16; b.u16 = h->u * 16; b.o16 = h->o * 16; b.e16 = h->e * 16; b.thresh16 = thresh16;
+		b.score = d_score; b.end_i = d_end_i; b.end_j = d_end_j; b.state = d_state;
+		b.ops = d_ops; b.ops_off = (const long long *)d_ops_off; b.nops = d_nops;
+		b.off_refb = P.off_refb; b.off_bound = P.off_bound; b.off_ptr = P.off_ptr; b.ptr_lanes = P.ptr_lanes;
+		const long long nwork = (npairs + 1) / 2;
+		long long grid16;
+		size_t dyn16 = 0;
+		if (small16) {
+			long long per_cu = (long long)((h->lds_per_cu - 1024) / std::max<size_t>(lds16, 512));
+			per_cu = std::max(1LL, std::min(per_cu, env_ll("AT_WAVES_PER_CU", 16)));
+			grid16 = std::min<long long>(nwork, per_cu * h->ncu);
+			dyn16 = lds16;
+			snprintf(h->cfg, sizeof h->cfg, "packed16 small(lds) rows/lane=%d lds=%zuB waves/cu=%lld grid=%lld (2 pairs/wave)", P.k, lds16, per_cu, grid16);
+		} else {
+			const long long per_cu = env_ll("AT_WAVES_PER_CU", 16);
+			const long long cap = env_ll("AT_WS_CAP_MB", 16384) << 20;
+			const long long slot_bytes = ((P.words + 63) & ~63LL) * 4;
+			grid16 = std::max(1LL, std::min(std::min<long long>(nwork, per_cu * h->ncu), cap / slot_bytes));
+			void *p = h->d_ws; size_t have = h->ws_bytes;
+			int rc = grow(h, &p, &have, (size_t)(grid16 * slot_bytes));
+			h->d_ws = (uint32_t *)p; h->ws_bytes = have;
+			if (rc) return rc;
+			b.ws = h->d_ws; b.ws_slot_words = slot_bytes / 4;
+			snprintf(h->cfg, sizeof h->cfg, "packed16 large(hbm) rows/lane=%d slot=%lldB grid=%lld (2 pairs/wave)", P.k, slot_bytes, grid16);
+		}
+		at_sweep16_fn fn16 = at_pick16(kmode, P.k, small16, tb);
+		if (dyn16 > 48 * 1024)
+			HIP_TRY(h, hipFuncSetAttribute((const void *)fn16, hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn16));
+		hipLaunchKernelGGL(fn16, dim3((unsigned)grid16), dim3(64), dyn16, stream, b);
+		HIP_TRY(h, hipGetLastError());
+		return AT_OK;
+	}
+
 	const Layout L = layout_for(kmode, bits, tb, max_len1, max_len2);
 	if (L.words >= (1LL << 30)) return fail(h, AT_ERR_RANGE, "pair too large: %lld workspace words", L.words);
 
@@ -331,7 +405,7 @@ extern "C" int at_align_batch_device(at_handle *h, int mode, int64_t npairs,
 	a.u_raw = h->u;
 	a.score = d_score; a.end_i = d_end_i; a.end_j = d_end_j; a.state = d_state;
 	a.ops = d_ops; a.ops_off = (const long long *)d_ops_off; a.nops = d_nops;
-	a.off_bound = L.off_bound; a.off_ptr = L.off_ptr;
+	a.off_bound = L.off_bound; a.off_ptr = L.off_ptr; a.ptr_lanes = L.ptr_lanes;
 	if (kmode == at::K_FITJ) {
 		int rc = ensure_sitemask(h, max_len2, stream);
 		if (rc) return rc;
@@ -345,7 +419,7 @@ extern "C" int at_align_batch_device(at_handle *h, int mode, int64_t npairs,
 		per_cu = std::max(1LL, std::min(per_cu, env_ll("AT_WAVES_PER_CU", 16)));
 		grid = std::min<long long>(npairs, per_cu * h->ncu);
 		dyn_lds = lds_bytes;
-		snprintf(h->cfg, sizeof h->cfg, "small(lds) bits=%d lds=%zuB waves/cu=%lld grid=%lld", bits, lds_bytes, per_cu, grid);
+		snprintf(h->cfg, sizeof h->cfg, "small(lds) bits=%d rows/lane=%d lds=%zuB waves/cu=%lld grid=%lld", bits, L.k, lds_bytes, per_cu, grid);
 	} else {
 		long long per_cu = env_ll("AT_WAVES_PER_CU", 16);
 		grid = std::min<long long>(npairs, per_cu * h->ncu);
@@ -359,9 +433,9 @@ extern "C" int at_align_batch_device(at_handle *h, int mode, int64_t npairs,
 		if (rc) return rc;
 		a.ws = h->d_ws;
 		a.ws_slot_words = slot_bytes / 4;
-		snprintf(h->cfg, sizeof h->cfg, "large(hbm) bits=%d slot=%lldB grid=%lld", bits, slot_bytes, grid);
+		snprintf(h->cfg, sizeof h->cfg, "large(hbm) bits=%d rows/lane=%d slot=%lldB grid=%lld", bits, L.k, slot_bytes, grid);
 	}
-	sweep_fn fn = bits == 2 ? pick1<2>(kmode, small, tb) : pick1<8>(kmode, small, tb);
+	at_sweep_fn fn = bits == 2 ? at_pick32_b2(kmode, L.k, small, tb) : at_pick32_b8(kmode, L.k, small, tb);
 	if (dyn_lds > 48 * 1024)
 		HIP_TRY(h, hipFuncSetAttribute((const void *)fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn_lds));
 	hipLaunchKernelGGL(fn, dim3((unsigned)grid), dim3(64), dyn_lds, stream, a);
@@ -384,6 +458,7 @@ extern "C" int at_align_batch(at_handle *h, int mode, int64_t npairs, const uint
 	if (tb && (!out_ops || !ops_off || !out_nops)) return fail(h, AT_ERR_ARG, "traceback wanted but ops buffers are NULL");
 
 	int max1 = 0, max2 = 0;
+	bool uniform = true;
 	int64_t ops_total = 0;
 	for (int64_t k = 0; k < npairs; ++k) {
 		if (len1[k] < 0 || len2[k] < 0) return fail(h, AT_ERR_ARG, "pair %lld: negative length", (long long)k);
@@ -394,6 +469,7 @@ extern "C" int at_align_batch(at_handle *h, int mode, int64_t npairs, const uint
 		if (mode == AT_MODE_FIT && len1[k] < 1) return fail(h, AT_ERR_DOMAIN, "pair %lld: fit needs a non-empty read", (long long)k);
 		if (mode == AT_MODE_OVERLAP && len2[k] < 1) return fail(h, AT_ERR_DOMAIN, "pair %lld: overlap needs a non-empty second sequence", (long long)k);
 		max1 = std::max(max1, len1[k]); max2 = std::max(max2, len2[k]);
+		if (len1[k] != len1[0] || len2[k] != len2[0]) uniform = false;
 		if (tb) ops_total = std::max<int64_t>(ops_total, ops_off[k] + len1[k] + len2[k]);
 	}
 	HIP_TRY(h, hipSetDevice(h->device));
@@ -434,7 +510,7 @@ extern "C" int at_align_batch(at_handle *h, int mode, int64_t npairs, const uint
 	HIP_TRY(h, hipMemcpyAsync(d_len1, len1, (size_t)npairs * 4, hipMemcpyHostToDevice, s));
 	HIP_TRY(h, hipMemcpyAsync(d_len2, len2, (size_t)npairs * 4, hipMemcpyHostToDevice, s));
 	if (tb) HIP_TRY(h, hipMemcpyAsync(d_opsoff, ops_off, (size_t)npairs * 8, hipMemcpyHostToDevice, s));
-	rc = at_align_batch_device(h, mode, npairs, d_words, bits, d_woff1, d_len1, d_woff2, d_len2, max1, max2, tb ? 1 : 0,
+	rc = at_align_batch_device(h, mode, npairs, d_words, bits, d_woff1, d_len1, d_woff2, d_len2, max1, max2, uniform ? 1 : 0, tb ? 1 : 0,
 	                           d_score, d_ei, d_ej, d_st, tb ? d_ops : nullptr, tb ? d_opsoff : nullptr, tb ? d_nops : nullptr, s);
 	if (rc) return rc;
 	HIP_TRY(h, hipMemcpyAsync(out_score, d_score, (size_t)npairs * 4, hipMemcpyDeviceToHost, s));

@@ -2,23 +2,26 @@
  * at_sweep.hip.h -- the anti-diagonal DP sweep + traceback kernel (gfx950).
  *
  * One 64-lane wavefront owns one alignment.  Query rows are cut into strips of
- * 64 rows; lane l of a strip owns row i = 64*s + l + 1 and, at step t, computes
- * column j = t - l + 1, so the wave walks anti-diagonals.  The three (four with
- * the fit jump state) DP values of the cell above arrive from lane l-1 through
- * a DPP wave_shr:1 move (the hardware form of __shfl_up(x, 1)); the left
- * neighbour is the lane's own previous step and lives in registers.  Lane 0
- * takes the row above its strip from a boundary row buffer that lane 63 of the
- * previous strip filled.  Reference sequence s2 is staged 2-bit (or 8-bit)
- * packed and read through a sliding 16-base register window; the lane's query
- * base is one register.  Pointers (4 bit per cell, 8 with the jump state) are
- * accumulated 8 steps per dword and stored time-major: ptr[strip][t/8][lane],
- * i.e. one fully coalesced 256-byte row per 8 anti-diagonals.
+ * 64*K rows; lane l of a strip owns the K consecutive rows 64*K*s + K*l + 1 ..
+ * + K and, at step t, computes their cells in column j = t - l + 1, so the wave
+ * walks anti-diagonals.  Inside a lane the K cells of a column are chained
+ * through registers (the cell above is the previous iteration of the unrolled
+ * row loop); across lanes the values of the cell above arrive from lane l-1
+ * through a DPP wave_shr:1 move (the hardware form of __shfl_up(x, 1)); the
+ * left neighbours are the lane's own previous step and live in registers.
+ * Lane 0 takes the row above its strip from a boundary row buffer that lane 63
+ * of the previous strip filled; 8 entries are prefetched per block of 8 steps
+ * and handed to lane 0 with a DPP row_shl.  The reference sequence s2 is staged
+ * 2-bit (or 8-bit) packed and read through a sliding register window (16 bases
+ * per int32); the lane's K query bases live in registers.  Pointers (4 bit per
+ * cell, 8 with the fit jump state) are accumulated 8 steps per dword and stored
+ * time-major: ptr[strip][t/8][row-in-lane][lane] -- for the HBM storage class
+ * one fully coalesced row per 8 anti-diagonals.
  *
- * Storage class `SMALL`: reference window source, boundary row and pointer
- * matrix all live in LDS (one wave per workgroup, no barriers needed -- LDS
- * operations of one wave execute in order).  `!SMALL`: the same three regions
- * live in a per-wave global workspace slot (HBM/L2) for pairs whose pointer
- * matrix does not fit LDS.
+ * Storage class `SMALL`: s2 window source, boundary row and pointer matrix all
+ * live in LDS (one wave per workgroup, no barriers -- LDS operations of one
+ * wave execute in order).  `!SMALL`: the same three regions live in a per-wave
+ * global workspace slot (HBM/L2) for pairs whose pointer matrix exceeds LDS.
  *
  * Arithmetic: the reference computes in fp64 that only ever holds integers or
  * -inf (alignment.h:58-62,483-486).  Here every score is an int32 scaled by 16
@@ -72,6 +75,7 @@ struct SweepArgs {
 	uint32_t *ws;                  /* !SMALL: per-wave workspace slots             */
 	long long ws_slot_words;
 	int off_bound, off_ptr;        /* word offsets of the regions inside a slot    */
+	int ptr_lanes;                 /* lanes per pointer row (min(64, ceil(max_l1/K))) */
 };
 
 extern __shared__ uint32_t at_lds[];
@@ -82,6 +86,13 @@ extern __shared__ uint32_t at_lds[];
 AT_DEV int shfl_up1(int old, int src)
 {
 	return __builtin_amdgcn_update_dpp(old, src, 0x138 /* wave_shr:1 */, 0xf, 0xf, false);
+}
+/* lane l reads lane l+N of its row of 16 (only lane 0 <- lane N is used) */
+template <int N>
+AT_DEV int row_shl(int v)
+{
+	if constexpr (N == 0) return v;
+	else return __builtin_amdgcn_update_dpp(0, v, 0x100 + N /* row_shl:N */, 0xf, 0xf, true);
 }
 AT_DEV int imax(int a, int b) { return a > b ? a : b; }
 AT_DEV int imin(int a, int b) { return a < b ? a : b; }
@@ -99,10 +110,20 @@ struct Slot {
 		if constexpr (SMALL) return at_lds[i];
 		else return g[i];
 	}
+	AT_DEV uint2 ld2(int i) const   /* i even: 8-byte aligned */
+	{
+		if constexpr (SMALL) return *reinterpret_cast<const uint2 *>(&at_lds[i]);
+		else return *reinterpret_cast<const uint2 *>(&g[i]);
+	}
 	AT_DEV void st(int i, uint32_t v) const
 	{
 		if constexpr (SMALL) at_lds[i] = v;
 		else g[i] = v;
+	}
+	AT_DEV void st2(int i, uint32_t v0, uint32_t v1) const
+	{
+		if constexpr (SMALL) *reinterpret_cast<uint2 *>(&at_lds[i]) = make_uint2(v0, v1);
+		else *reinterpret_cast<uint2 *>(&g[i]) = make_uint2(v0, v1);
 	}
 	/* make this wave's earlier stores visible to its later loads from other lanes */
 	AT_DEV void sync() const
@@ -143,31 +164,48 @@ AT_DEV int xo_of(int L, int M, int U, int J)
 	return x;
 }
 
-template <int MODE, int BITS, bool SMALL, bool TB>
+template <int K>
+AT_DEV int pick(const int (&v)[K], int r)   /* r is wave-uniform */
+{
+	int x = v[0];
+#pragma unroll
+	for (int q = 1; q < K; ++q)
+		if (r == q) x = v[q];
+	return x;
+}
+
+template <int MODE, int BITS, int K, bool SMALL, bool TB>
 __global__ __launch_bounds__(64) void at_sweep(const SweepArgs a)
 {
 	constexpr bool AFFINE = MODE <= K_FITJ;
 	constexpr bool HASJ = MODE == K_FITJ;
+	constexpr bool KEEPL = MODE == K_GLOBAL || MODE == K_FIT || MODE == K_FITJ;
 	constexpr int PB = HASJ ? 8 : 4;          /* pointer bits per cell        */
 	constexpr int SPD = 32 / PB;              /* steps per pointer dword      */
 	constexpr int RPB = kBlk / SPD;           /* pointer word rows per block  */
 	constexpr int BPW = 32 / BITS;            /* bases per packed word        */
 	constexpr int PADW = kPad / BPW;
+	constexpr int RS = 64 * K;                /* rows per strip               */
 	constexpr uint32_t BMASK = (1u << BITS) - 1u;
 
 	const int lane = threadIdx.x;
 	Slot<SMALL> mem;
 	mem.g = SMALL ? nullptr : a.ws + (long long)blockIdx.x * a.ws_slot_words;
 	const int m16 = a.m16, u16 = a.u16, o16 = a.o16, e16 = a.e16, g16 = a.g16;
+	const int NL = a.ptr_lanes;
+	/* keep the mismatch score in a VGPR the compiler will not re-materialise per step */
+	int u16v = MODE == K_EDIT ? a.u_raw : (MODE == K_OVERLAP ? u16 - o16 : u16);
+	asm volatile("" : "+v"(u16v));
+	const int m16s = MODE == K_EDIT ? 0 : (MODE == K_OVERLAP ? m16 - o16 : m16);
 
 	for (long long p = blockIdx.x; p < a.npairs; p += gridDim.x) {
 		const int l1 = uni(a.len1[p]);
 		const int l2 = uni(a.len2[p]);
 		const uint32_t *q_words = a.seq + a.woff1[p];
 		const uint32_t *r_words = a.seq + a.woff2[p];
-		const int nstrips = (l1 + 63) >> 6;
-		const int tbk = (l2 + 63 + kBlk - 1) / kBlk;   /* blocks per strip         */
-		const int wps = tbk * RPB;                     /* pointer word rows / strip */
+		const int nstrips = (l1 + RS - 1) / RS;
+		const int tbk = (l2 + 63 + kBlk - 1) / kBlk;   /* blocks per strip           */
+		const int wps = tbk * RPB * K;                 /* pointer word rows per strip */
 
 		/* ---- stage s2 (coalesced int32 reads) in front of kPad slack bases ---- */
 		{
@@ -179,8 +217,8 @@ __global__ __launch_bounds__(64) void at_sweep(const SweepArgs a)
 			if constexpr (AFFINE) {
 				int L, M, U, J;
 				border<MODE>(0, j, o16, e16, L, M, U, J);
-				mem.st(a.off_bound + 2 * j, (uint32_t)xo_of<MODE>(L, M, U, J));
-				mem.st(a.off_bound + 2 * j + 1, (uint32_t)imax((L | kTagL) + e16, (M | kTagM) + o16));
+				mem.st2(a.off_bound + 2 * j, (uint32_t)xo_of<MODE>(L, M, U, J),
+				        (uint32_t)imax((L | kTagL) + e16, (M | kTagM) + o16));
 			} else if constexpr (MODE == K_OVERLAP) {
 				mem.st(a.off_bound + 2 * j, (uint32_t)((j == 0 ? 0 : kNeg) + o16));   /* :937-938 */
 			} else {
@@ -189,70 +227,88 @@ __global__ __launch_bounds__(64) void at_sweep(const SweepArgs a)
 		}
 		mem.sync();
 
+		/* the cell (l1, .) lives in strip nstrips-1, lane lastlane, row-in-lane rl */
+		const int lastlane = l1 > 0 ? ((l1 - 1) % RS) / K : 0;
+		const int rl = l1 > 0 ? ((l1 - 1) % RS) % K : 0;
+
 		/* running results */
-		int best = INT32_MIN, best_tau = 0;        /* local: arg-max over M; fit/overlap: last row M */
-		int bestL = kNegThresh, bestL_tau = 0;     /* fit: last row L                                 */
-		int endL = kNeg, endM = kNeg, endU = kNeg; /* global: the three states of (l1,l2); edit: D    */
+		int best = INT32_MIN, best_i = INT32_MAX, best_j = INT32_MAX;   /* local arg-max; fit/overlap: last-row M scan */
+		int bestL = kNegThresh, bestL_j = 0;                            /* fit: last-row L scan                        */
 		if constexpr (MODE == K_FIT || MODE == K_FITJ) best = kNegThresh;
+		int Mo_l[K], U_l[K], Xl[K], L_l[K], Mg_l[K], J_l[K];   /* per-row left state (registers) */
 
 		for (int s = 0; s < nstrips; ++s) {
-			const int base = s << 6;
-			const int i = base + lane + 1;
-			const bool rowok = i <= l1;
-			const bool lastrow = i == l1;
-			/* my query base, replicated across the window width */
-			uint32_t qrep;
-			{
-				const int qi = rowok ? i - 1 : 0;
+			const int base = s * RS;
+			const int i0 = base + lane * K;                 /* 0-based index of my first row */
+			const int nl = imin(64, (l1 - base + K - 1) / K);   /* lanes holding at least one row */
+			const bool laststrip = s == nstrips - 1;
+			const bool wb = !laststrip;                     /* lane 63 feeds the next strip */
+			uint32_t qrep[K];
+			int best_r[K], bt_r[K];
+			uint32_t acc[K];
+#pragma unroll
+			for (int r = 0; r < K; ++r) {
+				const int qi = imin(i0 + r, l1 - 1);
 				const uint32_t qw = q_words[qi / BPW];
-				qrep = ((qw >> ((qi % BPW) * BITS)) & BMASK) * (BITS == 2 ? 0x55555555u : 0x01010101u);
+				qrep[r] = ((qw >> ((qi % BPW) * BITS)) & BMASK) * (BITS == 2 ? 0x55555555u : 0x01010101u);
+				best_r[r] = INT32_MIN; bt_r[r] = 0; acc[r] = 0;
+				const int i = i0 + r + 1;
+				if constexpr (AFFINE) {
+					int L, M, U, J;
+					border<MODE>(i, 0, o16, e16, L, M, U, J);
+					Mo_l[r] = (M | kTagM) + o16;
+					Mg_l[r] = (M | kTagM) + g16;
+					U_l[r] = U | kTagU;
+					J_l[r] = J;
+					L_l[r] = L | kTagL;
+					Xl[r] = xo_of<MODE>(L, M, U, J);
+				} else if constexpr (MODE == K_OVERLAP) {
+					Mo_l[r] = o16;           /* M(i,0) = 0 -> P = M + o */
+				} else {
+					Mo_l[r] = i;             /* D(i,0) = i */
+				}
 			}
-			/* column-0 state of my row, and what I hand to the lane below */
-			int Mo_l = 0, U_l = 0, Mg_l = 0, J_l = kNeg;   /* affine left state        */
-			int P_l = 0;                                   /* overlap / edit left state */
+			/* what the lane below sees as "row above, column 0", and my own diagonal */
 			int A_prev, B_prev = 0, Ad;
 			if constexpr (AFFINE) {
+				A_prev = Xl[K - 1];
 				int L, M, U, J;
-				border<MODE>(i, 0, o16, e16, L, M, U, J);
-				Mo_l = (M | kTagM) + o16;
-				Mg_l = (M | kTagM) + g16;
-				U_l = U | kTagU;
-				J_l = J;
-				A_prev = xo_of<MODE>(L, M, U, J);
 				border<MODE>(base, 0, o16, e16, L, M, U, J);
 				Ad = xo_of<MODE>(L, M, U, J);
 			} else if constexpr (MODE == K_OVERLAP) {
-				P_l = o16;               /* M(i,0) = 0  -> P = M + o */
-				A_prev = o16;
-				Ad = o16;
-				if (lastrow && l2 >= 1) { best = 0; best_tau = -1; }   /* M(l1,0) = 0 enters the scan :954 */
+				A_prev = o16; Ad = o16;
 			} else {
-				P_l = i;                 /* D(i,0) = i */
-				A_prev = i;
-				Ad = base;
+				A_prev = i0 + K; Ad = base;
 			}
-			/* lane 0 reads the row above from the boundary buffer, one step ahead */
-			int bx = 0, bl = 0;
-			if (lane == 0) {
-				bx = (int)mem.ld(a.off_bound + 2 * imin(1, l2));
-				if constexpr (AFFINE) bl = (int)mem.ld(a.off_bound + 2 * imin(1, l2) + 1);
-			}
-			uint32_t acc = 0;
+			/* boundary entries of columns t0+1+lane (lanes 0..7 matter), one block ahead */
+			auto load_bound = [&](int t0, int &bx, int &bl) {
+				const int jn = imin(t0 + 1 + (lane & 7), l2);
+				if constexpr (AFFINE) {
+					const uint2 v = mem.ld2(a.off_bound + 2 * jn);
+					bx = (int)v.x; bl = (int)v.y;
+				} else {
+					bx = (int)mem.ld(a.off_bound + 2 * jn); bl = 0;
+				}
+			};
+			int bx, bl, bxn, bln;
+			load_bound(0, bx, bl);
+			const int ptr_base = a.off_ptr + s * wps * NL;
 
 			for (int blk = 0; blk < tbk; ++blk) {
 				const int t0 = blk * kBlk;
-				/* ---- reference window: bases t0-lane .. t0-lane+7 ---- */
-				uint32_t xlo, xhi = 0;
+				load_bound(t0 + kBlk, bxn, bln);
+				/* ---- reference window: bases t0-lane .. t0-lane+7 against my K query bases ---- */
+				uint32_t xlo[K], xhi[K];
 				{
 					const int e0 = t0 - lane + kPad;
 					const int w = e0 / BPW;
 					const int sh = (e0 % BPW) * BITS;
 					const uint32_t w0 = mem.ld(w), w1 = mem.ld(w + 1);
-					xlo = __builtin_amdgcn_alignbit(w1, w0, sh) ^ qrep;
-					if constexpr (BITS == 8) {
-						const uint32_t w2 = mem.ld(w + 2);
-						xhi = __builtin_amdgcn_alignbit(w2, w1, sh) ^ qrep;
-					}
+					const uint32_t lo = __builtin_amdgcn_alignbit(w1, w0, sh);
+					uint32_t hi = 0;
+					if constexpr (BITS == 8) hi = __builtin_amdgcn_alignbit(mem.ld(w + 2), w1, sh);
+#pragma unroll
+					for (int r = 0; r < K; ++r) { xlo[r] = lo ^ qrep[r]; xhi[r] = hi ^ qrep[r]; }
 				}
 				uint32_t sm = 0;
 				if constexpr (HASJ) {
@@ -262,105 +318,133 @@ __global__ __launch_bounds__(64) void at_sweep(const SweepArgs a)
 				}
 				const int jm1_0 = t0 - lane;   /* 0-based column of step 0 of this block */
 
-				auto step = [&](auto KC) {
+				auto step = [&](auto KC, auto MASKED) {
 					constexpr int k = decltype(KC)::value;
+					constexpr bool masked = decltype(MASKED)::value;
 					const int t = t0 + k;
-					/* values of the cell above: lane-1's previous outputs (lane 0: boundary row) */
-					const int Aup = shfl_up1(bx, A_prev);
+					/* values of the cell above my first row: lane-1's previous outputs (lane 0: boundary row) */
+					const int Aup = shfl_up1(row_shl<k>(bx), A_prev);
 					int Bup = 0;
-					if constexpr (AFFINE) Bup = shfl_up1(bl, B_prev);
-					/* lane 0 prefetches the boundary entry of the next step */
-					if (lane == 0) {
-						const int jn = imin(t + 2, l2);
-						bx = (int)mem.ld(a.off_bound + 2 * jn);
-						if constexpr (AFFINE) bl = (int)mem.ld(a.off_bound + 2 * jn + 1);
-					}
+					if constexpr (AFFINE) Bup = shfl_up1(row_shl<k>(bl), B_prev);
 					const int jm1 = jm1_0 + k;
-					const bool active = rowok && (unsigned)jm1 < (unsigned)l2;
-					uint32_t nib = 0;   /* pointer bits of this cell (don't care when inactive) */
+					bool active = true;
+					if constexpr (masked) active = lane < nl && (unsigned)jm1 < (unsigned)l2;
+					uint32_t nib[K];
+#pragma unroll
+					for (int r = 0; r < K; ++r) nib[r] = 0;
 					if (active) {
-						uint32_t mis;
-						if constexpr (BITS == 2) mis = (xlo >> (2 * k)) & 3u;
-						else mis = ((k < 4 ? xlo : xhi) >> (8 * (k & 3))) & 0xffu;
-						if constexpr (AFFINE) {
-							const int s16 = mis ? u16 : m16;
-							int Mraw = Ad + s16;
-							if constexpr (MODE == K_LOCAL) Mraw = imax(Mraw, 0);
-							const int Mc = (Mraw & ~15) | kTagM;
-							const int Lraw = Bup;
-							const int Lc = Lraw | kTagL;
-							const int Uraw = imax(Mo_l, U_l + e16);
-							const int Uc = (Uraw & ~15) | kTagU;
-							int Jraw = 0, Jc = kNeg;
-							if constexpr (HASJ) {
-								const bool open_ok = (sm >> k) & 1u;
-								Jraw = open_ok ? imax(Mg_l, J_l) : J_l;
-								Jc = Jraw & ~15;
-							}
-							const int Mo = Mc + o16;
-							int Xo = imax3(Lc, Mc, Uc);
-							if constexpr (HASJ) Xo = imax(Xo, Jc);
-							const int Ld = imax(Lc + e16, Mo);
-							/* left state for my next column, outputs for the lane below */
-							Mo_l = Mo; U_l = Uc;
-							if constexpr (HASJ) { Mg_l = Mc + g16; J_l = Jc; }
-							A_prev = Xo; B_prev = Ld;
-							if constexpr (TB) {
-								nib = bfi(3u, (uint32_t)Mraw, (uint32_t)Lraw);
-								nib = bfi(7u, nib, (uint32_t)Uraw);
-								if constexpr (HASJ) nib = (nib & 15u) | (((uint32_t)Jraw & 8u) << 1);
-							}
-							if constexpr (MODE == K_LOCAL) {
-								if (Mc > best) { best = Mc; best_tau = s * (tbk * kBlk) + t; }   /* :830-833 */
-							} else if constexpr (MODE == K_GLOBAL) {
-								if (lastrow && jm1 + 1 == l2) { endL = Lc; endM = Mc; endU = Uc; }
-							} else {
-								/* fit end-cell scan over j = 1..l2-1 of row l1 (:676-690; j = 0 holds -inf) */
-								if (lastrow && jm1 + 1 < l2) {
-									if (Mc > best) { best = Mc; best_tau = t; }
-									if (Lc > bestL) { bestL = Lc; bestL_tau = t; }
+						if constexpr (MODE == K_FIT || MODE == K_FITJ || MODE == K_OVERLAP) {
+							/* end-cell scan of row l1 over columns 0..l2-1 (:676-690, :954-959), one column
+							 * behind the sweep: the left state still holds column j-1 = jm1 */
+							if (laststrip) {
+								const int vM = pick<K>(Mo_l, rl) - o16;
+								if (lane == lastlane && vM > best) { best = vM; best_j = jm1; }
+								if constexpr (AFFINE) {
+									const int vL = pick<K>(L_l, rl);
+									if (lane == lastlane && vL > bestL) { bestL = vL; bestL_j = jm1; }
 								}
 							}
-							if (lane == 63) {
-								mem.st(a.off_bound + 2 * (jm1 + 1), (uint32_t)Xo);
-								mem.st(a.off_bound + 2 * (jm1 + 1) + 1, (uint32_t)Ld);
+						}
+						int diag = Ad, up = Aup, lraw = Bup;
+#pragma unroll
+						for (int r = 0; r < K; ++r) {
+							uint32_t mis;
+							if constexpr (BITS == 2) mis = (xlo[r] >> (2 * k)) & 3u;
+							else mis = ((k < 4 ? xlo[r] : xhi[r]) >> (8 * (k & 3))) & 0xffu;
+							const int s16 = mis ? u16v : m16s;
+							if constexpr (AFFINE) {
+								int Mraw = diag + s16;
+								if constexpr (MODE == K_LOCAL) Mraw = imax(Mraw, 0);
+								const int Mc = (Mraw & ~15) | kTagM;
+								const int Lc = lraw | kTagL;
+								const int Uraw = imax(Mo_l[r], U_l[r] + e16);
+								const int Uc = (Uraw & ~15) | kTagU;
+								int Jraw = 0, Jc = kNeg;
+								if constexpr (HASJ) {
+									const bool open_ok = (sm >> k) & 1u;
+									Jraw = open_ok ? imax(Mg_l[r], J_l[r]) : J_l[r];
+									Jc = Jraw & ~15;
+								}
+								const int Mo = Mc + o16;
+								int Xo = imax3(Lc, Mc, Uc);
+								if constexpr (HASJ) Xo = imax(Xo, Jc);
+								const int Ld = imax(Lc + e16, Mo);
+								if constexpr (TB) {
+									nib[r] = bfi(3u, (uint32_t)Mraw, (uint32_t)lraw);
+									nib[r] = bfi(7u, nib[r], (uint32_t)Uraw);
+									if constexpr (HASJ) nib[r] = (nib[r] & 15u) | (((uint32_t)Jraw & 8u) << 1);
+								}
+								if constexpr (MODE == K_LOCAL) {
+									if (Mc > best_r[r]) { best_r[r] = Mc; bt_r[r] = t; }   /* :830-833 */
+								}
+								/* hand down / right */
+								diag = Xl[r];
+								Xl[r] = Xo;
+								lraw = Ld;
+								up = Xo;
+								Mo_l[r] = Mo; U_l[r] = Uc;
+								if constexpr (KEEPL) L_l[r] = Lc;
+								if constexpr (HASJ) { Mg_l[r] = Mc + g16; J_l[r] = Jc; }
+							} else if constexpr (MODE == K_OVERLAP) {
+								/* max5(M(i,j-1)+o, M(i-1,j-1)+s, M(i-1,j)+o): LEFT, DIAGONAL, RIGHT  :944 */
+								const int old = Mo_l[r];
+								const int Mraw = imax3(old | 3, (diag + s16) | 2, up | 1);
+								const int P = (Mraw & ~15) + o16;
+								nib[r] = (uint32_t)Mraw;
+								Mo_l[r] = P; diag = old; up = P;
+							} else {
+								/* min3(D(i,j-1)+1, D(i-1,j-1)+cost, D(i-1,j)+1)  :306-309 */
+								const int old = Mo_l[r];
+								const int D = imin3(old + 1, diag + s16, up + 1);
+								Mo_l[r] = D; diag = old; up = D;
 							}
-						} else if constexpr (MODE == K_OVERLAP) {
-							/* max5(M(i,j-1)+o, M(i-1,j-1)+s, M(i-1,j)+o): LEFT, DIAGONAL, RIGHT  :944 */
-							const int sp = mis ? (u16 - o16) : (m16 - o16);
-							const int Mraw = imax3(P_l | 3, (Ad + sp) | 2, Aup | 1);
-							const int Mc = Mraw & ~15;
-							const int P = Mc + o16;
-							P_l = P; A_prev = P;
-							nib = (uint32_t)Mraw;
-							if (lastrow && jm1 + 1 < l2 && Mc > best) { best = Mc; best_tau = t; }
-							if (lane == 63) mem.st(a.off_bound + 2 * (jm1 + 1), (uint32_t)P);
-						} else {
-							/* min3(D(i,j-1)+1, D(i-1,j-1)+cost, D(i-1,j)+1)  :306-309 */
-							const int cost = mis ? a.u_raw : 0;
-							const int D = imin3(P_l + 1, Ad + cost, Aup + 1);
-							P_l = D; A_prev = D;
-							if (lastrow && jm1 + 1 == l2) endM = D;
-							if (lane == 63) mem.st(a.off_bound + 2 * (jm1 + 1), (uint32_t)D);
+						}
+						A_prev = up; B_prev = lraw;
+						if (wb && lane == 63) {
+							if constexpr (AFFINE) mem.st2(a.off_bound + 2 * (jm1 + 1), (uint32_t)up, (uint32_t)lraw);
+							else mem.st(a.off_bound + 2 * (jm1 + 1), (uint32_t)up);
 						}
 					}
 					Ad = Aup;
 					/* every lane pushes every step so that nibble k of a word is step k */
-					if constexpr (TB) acc = __builtin_amdgcn_alignbit(nib, acc, PB);
-					if constexpr (TB && SPD < kBlk) {
-						if ((k + 1) % SPD == 0)
-							mem.st(a.off_ptr + ((s * wps + blk * RPB + k / SPD) << 6) + lane, acc);
+					if constexpr (TB) {
+#pragma unroll
+						for (int r = 0; r < K; ++r) acc[r] = __builtin_amdgcn_alignbit(nib[r], acc[r], PB);
+						if constexpr (SPD < kBlk) {
+							if ((k + 1) % SPD == 0 && lane < NL) {
+#pragma unroll
+								for (int r = 0; r < K; ++r)
+									mem.st(ptr_base + ((blk * RPB + k / SPD) * K + r) * NL + lane, acc[r]);
+							}
+						}
 					}
 				};
-				step(std::integral_constant<int, 0>{});
-				step(std::integral_constant<int, 1>{});
-				step(std::integral_constant<int, 2>{});
-				step(std::integral_constant<int, 3>{});
-				step(std::integral_constant<int, 4>{});
-				step(std::integral_constant<int, 5>{});
-				step(std::integral_constant<int, 6>{});
-				step(std::integral_constant<int, 7>{});
-				if constexpr (TB && SPD == kBlk) mem.st(a.off_ptr + ((s * wps + blk) << 6) + lane, acc);
+				using T = std::true_type;
+				using F = std::false_type;
+#define AT_STEPS(M)                                                                                      \
+	step(std::integral_constant<int, 0>{}, M{}); step(std::integral_constant<int, 1>{}, M{});            \
+	step(std::integral_constant<int, 2>{}, M{}); step(std::integral_constant<int, 3>{}, M{});            \
+	step(std::integral_constant<int, 4>{}, M{}); step(std::integral_constant<int, 5>{}, M{});            \
+	step(std::integral_constant<int, 6>{}, M{}); step(std::integral_constant<int, 7>{}, M{});
+				/* steady block: every lane that owns rows is inside the matrix for all 8 steps
+				 * (lanes >= nl then compute cells nobody reads: nothing of theirs is stored or merged) */
+				if (t0 >= nl - 1 && t0 + kBlk <= l2) { AT_STEPS(F) }
+				else { AT_STEPS(T) }
+#undef AT_STEPS
+				if constexpr (TB && SPD == kBlk) {
+					if (lane < NL) {
+#pragma unroll
+						for (int r = 0; r < K; ++r) mem.st(ptr_base + (blk * K + r) * NL + lane, acc[r]);
+					}
+				}
+				bx = bxn; bl = bln;
+			}
+			if constexpr (MODE == K_LOCAL) {
+				/* rows ascend inside a lane; strict '>' keeps the first in row-major order */
+#pragma unroll
+				for (int r = 0; r < K; ++r) {
+					if (i0 + r < l1 && best_r[r] > best) { best = best_r[r]; best_i = i0 + r + 1; best_j = bt_r[r] - lane + 1; }
+				}
 			}
 			mem.sync();
 		}
@@ -368,17 +452,9 @@ __global__ __launch_bounds__(64) void at_sweep(const SweepArgs a)
 		/* ================= end cell (uniform from here on) ================= */
 		int sc16 = 0, ci = 0, cj = 0, st = 2;   /* st: 3 LOW, 2 MID, 1 UPP, 0 JUMP/HOME */
 		bool ok = true;
-		const int own = (l1 - 1) & 63;          /* lane that owns row l1 */
 		if constexpr (MODE == K_LOCAL) {
 			/* first cell in row-major order among the maxima: (max M, min i, min j) */
-			int bi = 0, bj = 0;
-			{
-				const int period = tbk * kBlk;
-				const int bs = best_tau / period, bt = best_tau % period;
-				bi = (bs << 6) + lane + 1;
-				bj = bt - lane + 1;
-				if (best == INT32_MIN) { bi = INT32_MAX; bj = INT32_MAX; }
-			}
+			int bi = best_i, bj = best_j;
 			for (int d = 32; d >= 1; d >>= 1) {
 				const int ob = __shfl_xor(best, d), oi = __shfl_xor(bi, d), oj = __shfl_xor(bj, d);
 				const bool take = ob > best || (ob == best && (oi < bi || (oi == bi && oj < bj)));
@@ -389,9 +465,9 @@ __global__ __launch_bounds__(64) void at_sweep(const SweepArgs a)
 		} else if constexpr (MODE == K_GLOBAL) {
 			int eL, eM, eU;
 			if (l1 >= 1 && l2 >= 1) {
-				eL = __builtin_amdgcn_readlane(endL, own);
-				eM = __builtin_amdgcn_readlane(endM, own);
-				eU = __builtin_amdgcn_readlane(endU, own);
+				eL = __builtin_amdgcn_readlane(pick<K>(L_l, rl), lastlane);
+				eM = __builtin_amdgcn_readlane(pick<K>(Mo_l, rl), lastlane) - o16;
+				eU = __builtin_amdgcn_readlane(pick<K>(U_l, rl), lastlane);
 			} else {
 				int L, M, U, J;
 				border<MODE>(l1, l2, o16, e16, L, M, U, J);
@@ -400,22 +476,22 @@ __global__ __launch_bounds__(64) void at_sweep(const SweepArgs a)
 			const int x = imax3(eL, eM, eU);   /* max5(L,M,U) first-wins :466 */
 			sc16 = x; st = x & 3; ci = l1; cj = l2;
 		} else if constexpr (MODE == K_FIT || MODE == K_FITJ) {
-			const int bM = __builtin_amdgcn_readlane(best, own), tM = __builtin_amdgcn_readlane(best_tau, own);
-			const int bL = __builtin_amdgcn_readlane(bestL, own), tL = __builtin_amdgcn_readlane(bestL_tau, own);
+			const int bM = __builtin_amdgcn_readlane(best, lastlane), jM = __builtin_amdgcn_readlane(best_j, lastlane);
+			const int bL = __builtin_amdgcn_readlane(bestL, lastlane), jL = __builtin_amdgcn_readlane(bestL_j, lastlane);
 			ci = l1;
-			if ((bL >> kShift) > (bM >> kShift) && bL > kNegThresh) { sc16 = bL; st = 3; cj = tL - own + 1; }   /* L only if strictly greater :684-690 */
-			else { sc16 = bM; st = 2; cj = tM - own + 1; }
+			if ((bL >> kShift) > (bM >> kShift) && bL > kNegThresh) { sc16 = bL; st = 3; cj = jL; }   /* L only if strictly greater :684-690 */
+			else { sc16 = bM; st = 2; cj = jM; }
 			ok = sc16 > kNegThresh;
 		} else if constexpr (MODE == K_OVERLAP) {
 			if (l1 >= 1) {
-				const int bM = __builtin_amdgcn_readlane(best, own), tM = __builtin_amdgcn_readlane(best_tau, own);
-				sc16 = bM; cj = tM < 0 ? 0 : tM - own + 1;
+				sc16 = __builtin_amdgcn_readlane(best, lastlane);
+				cj = __builtin_amdgcn_readlane(best_j, lastlane);
 			} else { sc16 = 0; cj = 0; }   /* row 0: only M(0,0)=0 is finite */
 			ci = l1; st = 2;
 			ok = l2 >= 1;
 		} else {
 			int d;
-			if (l1 >= 1 && l2 >= 1) d = __builtin_amdgcn_readlane(endM, own);
+			if (l1 >= 1 && l2 >= 1) d = __builtin_amdgcn_readlane(pick<K>(Mo_l, rl), lastlane);
 			else d = l1 + l2;              /* border: D(i,0)=i, D(0,j)=j */
 			sc16 = d << kShift; ci = l1; cj = l2;
 		}
@@ -432,9 +508,10 @@ __global__ __launch_bounds__(64) void at_sweep(const SweepArgs a)
 				++cnt;
 			};
 			auto fetch = [&](int ii, int jj) -> uint32_t {
-				const int ss = (ii - 1) >> 6, ln = (ii - 1) & 63;
+				const int ss = (ii - 1) / RS, li = (ii - 1) % RS;
+				const int ln = li / K, r = li % K;
 				const int t = (jj - 1) + ln;
-				const uint32_t w = mem.ld(a.off_ptr + ((ss * wps + t / SPD) << 6) + ln);
+				const uint32_t w = mem.ld(a.off_ptr + (ss * wps + (t / SPD) * K + r) * NL + ln);
 				return (uint32_t)uni((int)((w >> ((t % SPD) * PB)) & ((1u << PB) - 1u)));
 			};
 			int guard = l1 + l2 + 2;

@@ -1,0 +1,405 @@
+/*
+ * at_sweep16.hip.h -- packed-int16 variant of the anti-diagonal sweep (gfx950).
+ *
+ * Same geometry as at_sweep.hip.h (one wavefront per sweep, K rows per lane,
+ * DPP wave_shr:1 for the cell above, time-major pointers), but every 32-bit
+ * register carries TWO alignments of the same shape (l1, l2): pair A in bits
+ * [15:0], pair B in bits [31:16].  gfx950 issues v_pk_add_i16 / v_pk_max_i16 at
+ * the same rate as the 32-bit integer max (measured: tools/valu_rate*.hip), and
+ * the tag/clean/pointer logic is bitwise, so one instruction stream fills two
+ * DP matrices.  Used for batches of uniform shape whose scores provably fit:
+ * 16 * (|score| range) < 2^15 with the -inf sentinel at -32768 (saturating
+ * adds keep it there); everything else takes the int32 kernel.
+ *
+ * Score lookup: s2 is staged in LDS one BYTE per base (codes 0..3, unpacked
+ * from the 2-bit HBM format); x = window ^ query gives 0 for a match; one
+ * v_perm_b32 gathers step k's two x bytes into a selector and a second one
+ * reads the 16-bit scores of both pairs from a byte LUT {m,u,u,u}.
+ *
+ * Tags, pointer bits and tie-breaking are exactly those of at_sweep.hip.h,
+ * per 16-bit half (reference max5 first-wins order, alignment.h:90-100).
+ * Local arg-max (alignment.h:830-833, first in row-major order) is tracked
+ * once per step: the K cells of the column are reduced with the row index in
+ * the (otherwise constant) tag bits, then folded into a per-lane running
+ * (best, step) pair with a packed compare built from a saturating subtract.
+ */
+#pragma once
+#include "at_sweep.hip.h"
+
+namespace at {
+
+typedef short s16x2 __attribute__((ext_vector_type(2)));
+
+struct Sweep16Args {
+	long long npairs;
+	const uint32_t *seq;
+	const long long *woff1;
+	const long long *woff2;
+	int l1, l2;                    /* uniform shape of the whole batch                    */
+	int m16, u16, o16, e16;        /* scores * 16 (each fits int16)                       */
+	int thresh16;                  /* values <= thresh16 are "-inf" (fit end-cell scan)   */
+	int *score, *end_i, *end_j, *state;
+	uint8_t *ops;
+	const long long *ops_off;
+	int *nops;
+	uint32_t *ws;
+	long long ws_slot_words;
+	int off_refb, off_bound, off_ptr;
+	int ptr_lanes;
+};
+
+AT_DEV uint32_t pk2(int v) { return ((uint32_t)v & 0xffffu) | ((uint32_t)v << 16); }
+AT_DEV uint32_t padd(uint32_t a, uint32_t b)
+{
+	return __builtin_bit_cast(uint32_t, __builtin_elementwise_add_sat(__builtin_bit_cast(s16x2, a), __builtin_bit_cast(s16x2, b)));
+}
+AT_DEV uint32_t psub(uint32_t a, uint32_t b)
+{
+	return __builtin_bit_cast(uint32_t, __builtin_elementwise_sub_sat(__builtin_bit_cast(s16x2, a), __builtin_bit_cast(s16x2, b)));
+}
+AT_DEV uint32_t pmax(uint32_t a, uint32_t b)
+{
+	return __builtin_bit_cast(uint32_t, __builtin_elementwise_max(__builtin_bit_cast(s16x2, a), __builtin_bit_cast(s16x2, b)));
+}
+/* 0xffff in every half that is negative */
+AT_DEV uint32_t pneg(uint32_t a)
+{
+	return __builtin_bit_cast(uint32_t, __builtin_bit_cast(s16x2, a) >> (s16x2)(15));
+}
+AT_DEV int half(uint32_t v, int h) { return (int)(short)(h ? (v >> 16) : (v & 0xffffu)); }
+
+constexpr uint32_t kClean2 = 0xfff0fff0u, kTagL2 = 0x000f000fu, kTagM2 = 0x000a000au, kTagU2 = 0x00010001u;
+constexpr int kNeg16 = -32768;
+
+/* border cells, scaled by 16, int16 range (see border<> in at_sweep.hip.h) */
+template <int MODE>
+AT_DEV void border16(int i, int j, int o16, int e16, int &L, int &M, int &U)
+{
+	if constexpr (MODE == K_GLOBAL) {
+		if (i == 0 && j == 0) { L = o16; M = 0; U = o16; }
+		else if (j == 0) { L = o16 + e16 * i; M = kNeg16; U = kNeg16; }
+		else { L = kNeg16; M = kNeg16; U = o16 + e16 * j; }
+	} else if constexpr (MODE == K_LOCAL) {
+		L = 0; M = 0; U = 0;
+	} else {
+		if (i == 0) { L = kNeg16; M = 0; U = 0; }
+		else { L = kNeg16; M = kNeg16; U = kNeg16; }
+	}
+}
+AT_DEV int sat16(int v) { return v < -32768 ? -32768 : (v > 32767 ? 32767 : v); }
+
+template <int K>
+AT_DEV uint32_t pick(const uint32_t (&v)[K], int r)
+{
+	uint32_t x = v[0];
+#pragma unroll
+	for (int q = 1; q < K; ++q)
+		if (r == q) x = v[q];
+	return x;
+}
+
+template <int MODE, int K, bool SMALL, bool TB>
+__global__ __launch_bounds__(64) void at_sweep16(const Sweep16Args a)
+{
+	static_assert(MODE == K_GLOBAL || MODE == K_LOCAL || MODE == K_FIT, "packed path: 3-state modes without the jump state");
+	constexpr int RS = 64 * K;
+	constexpr int PADW = kPad / 4;            /* s2 bytes: 4 per word */
+	const int lane = threadIdx.x;
+	Slot<SMALL> mem;
+	mem.g = SMALL ? nullptr : a.ws + (long long)blockIdx.x * a.ws_slot_words;
+	const int l1 = a.l1, l2 = a.l2, NL = a.ptr_lanes;
+	const int o16 = a.o16, e16 = a.e16;
+	uint32_t o2 = pk2(a.o16), e2 = pk2(a.e16);
+	/* byte LUT for v_perm: pool bytes 0..3 = low bytes of {m,u,u,u}, 4..7 = high bytes */
+	uint32_t lut_lo = ((uint32_t)a.m16 & 0xffu) | (((uint32_t)a.u16 & 0xffu) * 0x01010100u);
+	uint32_t lut_hi = (((uint32_t)a.m16 >> 8) & 0xffu) | ((((uint32_t)a.u16 >> 8) & 0xffu) * 0x01010100u);
+	asm volatile("" : "+v"(o2), "+v"(e2), "+v"(lut_lo), "+v"(lut_hi));
+	const int nstrips = (l1 + RS - 1) / RS;
+	const int tbk = (l2 + 63 + kBlk - 1) / kBlk;
+	const int wps = tbk * 2 * K;              /* pointer word rows per strip: 4 steps per word */
+	const int lastlane = l1 > 0 ? ((l1 - 1) % RS) / K : 0;
+	const int rl = l1 > 0 ? ((l1 - 1) % RS) % K : 0;
+	const long long nwork = (a.npairs + 1) >> 1;
+
+	for (long long wk = blockIdx.x; wk < nwork; wk += gridDim.x) {
+		const long long pA = 2 * wk;
+		const long long pB = (2 * wk + 1 < a.npairs) ? 2 * wk + 1 : pA;
+		const uint32_t *qA = a.seq + a.woff1[pA], *qB = a.seq + a.woff1[pB];
+		const uint32_t *rA = a.seq + a.woff2[pA], *rB = a.seq + a.woff2[pB];
+
+		/* ---- stage both s2 as bytes (coalesced int32 reads of the 2-bit words) ---- */
+		{
+			const int nw2 = (l2 + 15) >> 4;
+			for (int w = lane; w < nw2; w += 64) {
+				const uint32_t va = rA[w], vb = rB[w];
+#pragma unroll
+				for (int q = 0; q < 4; ++q) {
+					const uint32_t ba = (va >> (8 * q)) & 0xffu, bb = (vb >> (8 * q)) & 0xffu;
+					mem.st(PADW + 4 * w + q, (ba & 3u) | ((ba & 0xcu) << 6) | ((ba & 0x30u) << 12) | ((ba & 0xc0u) << 18));
+					mem.st(a.off_refb + PADW + 4 * w + q, (bb & 3u) | ((bb & 0xcu) << 6) | ((bb & 0x30u) << 12) | ((bb & 0xc0u) << 18));
+				}
+			}
+		}
+		/* ---- boundary row 0 (identical for both pairs) ---- */
+		for (int j = lane; j <= l2; j += 64) {
+			int L, M, U;
+			border16<MODE>(0, j, o16, e16, L, M, U);
+			const int x = imax3(L | kTagL, M | kTagM, U | kTagU);
+			const int ld = imax(sat16((L | kTagL) + e16), sat16((M | kTagM) + o16));
+			mem.st2(a.off_bound + 2 * j, pk2(x), pk2(ld));
+		}
+		mem.sync();
+
+		/* running results, per half */
+		int gbi[2] = {INT32_MAX, INT32_MAX}, gbj[2] = {INT32_MAX, INT32_MAX}, gbs[2] = {INT32_MIN, INT32_MIN};
+		uint32_t bestM = pk2(a.thresh16), bestMj = 0, bestL = pk2(a.thresh16), bestLj = 0;   /* fit scans */
+		uint32_t Mo_l[K], U_l[K], Xl[K], L_l[K];
+
+		for (int s = 0; s < nstrips; ++s) {
+			const int base = s * RS;
+			const int i0 = base + lane * K;
+			const int nl = imin(64, (l1 - base + K - 1) / K);
+			const bool laststrip = s == nstrips - 1;
+			const bool wb = !laststrip;
+			uint32_t qrA[K], qrB[K], acc[K], keymask[K], rowtag[K];
+#pragma unroll
+			for (int r = 0; r < K; ++r) {
+				const int qi = imin(i0 + r, l1 - 1);
+				qrA[r] = ((qA[qi >> 4] >> ((qi & 15) * 2)) & 3u) * 0x01010101u;
+				qrB[r] = ((qB[qi >> 4] >> ((qi & 15) * 2)) & 3u) * 0x01010101u;
+				acc[r] = 0;
+				const bool valid = i0 + r < l1;
+				keymask[r] = valid ? kClean2 : 0u;
+				rowtag[r] = valid ? (uint32_t)(K - 1 - r) * 0x00010001u : 0x80008000u;
+				int L, M, U;
+				border16<MODE>(i0 + r + 1, 0, o16, e16, L, M, U);
+				L = sat16(L);
+				Mo_l[r] = pk2(sat16((M | kTagM) + o16));
+				U_l[r] = pk2(U | kTagU);
+				L_l[r] = pk2(L | kTagL);
+				Xl[r] = pk2(imax3(L | kTagL, M | kTagM, U | kTagU));
+			}
+			uint32_t A_prev = Xl[K - 1], B_prev = 0, Ad;
+			{
+				int L, M, U;
+				border16<MODE>(base, 0, o16, e16, L, M, U);
+				L = sat16(L);
+				Ad = pk2(imax3(L | kTagL, M | kTagM, U | kTagU));
+			}
+			uint32_t best = 0x80008000u, bt = 0;   /* local: per-lane (key, step) of this strip */
+			auto load_bound = [&](int t0, uint32_t &bx, uint32_t &bl) {
+				const int jn = imin(t0 + 1 + (lane & 7), l2);
+				const uint2 v = mem.ld2(a.off_bound + 2 * jn);
+				bx = v.x; bl = v.y;
+			};
+			uint32_t bx, bl, bxn, bln;
+			load_bound(0, bx, bl);
+			const int ptr_base = a.off_ptr + s * wps * NL;
+
+			for (int blk = 0; blk < tbk; ++blk) {
+				const int t0 = blk * kBlk;
+				load_bound(t0 + kBlk, bxn, bln);
+				/* ---- s2 windows: bytes t0-lane .. t0-lane+7 of both pairs, xor my K query bases ---- */
+				uint32_t xA[2][K], xB[2][K];
+				{
+					const int e0 = t0 - lane + kPad;
+					const int w = e0 >> 2;
+					const int sh = (e0 & 3) * 8;
+					const uint32_t a0 = mem.ld(w), a1 = mem.ld(w + 1), a2 = mem.ld(w + 2);
+					const uint32_t b0 = mem.ld(a.off_refb + w), b1 = mem.ld(a.off_refb + w + 1), b2 = mem.ld(a.off_refb + w + 2);
+					const uint32_t alo = __builtin_amdgcn_alignbit(a1, a0, sh), ahi = __builtin_amdgcn_alignbit(a2, a1, sh);
+					const uint32_t blo = __builtin_amdgcn_alignbit(b1, b0, sh), bhi = __builtin_amdgcn_alignbit(b2, b1, sh);
+#pragma unroll
+					for (int r = 0; r < K; ++r) {
+						xA[0][r] = alo ^ qrA[r]; xA[1][r] = ahi ^ qrA[r];
+						xB[0][r] = blo ^ qrB[r]; xB[1][r] = bhi ^ qrB[r];
+					}
+				}
+				const int jm1_0 = t0 - lane;
+
+				auto step = [&](auto KC, auto MASKED) {
+					constexpr int k = decltype(KC)::value;
+					constexpr bool masked = decltype(MASKED)::value;
+					constexpr int kk = k & 3, hw = k >> 2;
+					/* selector picking byte kk of xA (pool 0..3) twice and of xB (pool 4..7) twice */
+					constexpr uint32_t SELK = (uint32_t)kk * 0x00000101u + (uint32_t)(4 + kk) * 0x01010000u;
+					const int t = t0 + k;
+					const uint32_t Aup = (uint32_t)shfl_up1((int)row_shl<k>((int)bx), (int)A_prev);
+					const uint32_t Bup = (uint32_t)shfl_up1((int)row_shl<k>((int)bl), (int)B_prev);
+					const int jm1 = jm1_0 + k;
+					bool active = true;
+					if constexpr (masked) active = lane < nl && (unsigned)jm1 < (unsigned)l2;
+					uint32_t pbyte[K];
+#pragma unroll
+					for (int r = 0; r < K; ++r) pbyte[r] = 0;
+					if (active) {
+						if constexpr (MODE == K_FIT) {
+							/* end-cell scan of row l1, columns 0..l2-1 (:676-690), one column behind the sweep;
+							 * every lane scans its own row rl, only lane `lastlane` is read at the end */
+							if (laststrip) {
+								const uint32_t jpk = pk2(jm1);
+								const uint32_t vM = psub(pick<K>(Mo_l, rl), o2);
+								uint32_t g = pneg(psub(bestM, vM));
+								bestMj = bfi(g, jpk, bestMj); bestM = pmax(bestM, vM);
+								const uint32_t vL = pick<K>(L_l, rl);
+								g = pneg(psub(bestL, vL));
+								bestLj = bfi(g, jpk, bestLj); bestL = pmax(bestL, vL);
+							}
+						}
+						uint32_t diag = Ad, lraw = Bup, up = 0, cmax = 0;
+#pragma unroll
+						for (int r = 0; r < K; ++r) {
+							uint32_t sel = __builtin_amdgcn_perm(xB[hw][r], xA[hw][r], SELK) | 0x04000400u;
+							const uint32_t S = __builtin_amdgcn_perm(lut_hi, lut_lo, sel);
+							uint32_t Mraw = padd(diag, S);
+							if constexpr (MODE == K_LOCAL) Mraw = pmax(Mraw, 0u);
+							const uint32_t Mc = (Mraw & kClean2) | kTagM2;
+							const uint32_t Lc = lraw | kTagL2;
+							const uint32_t Uraw = pmax(Mo_l[r], padd(U_l[r], e2));
+							const uint32_t Uc = (Uraw & kClean2) | kTagU2;
+							const uint32_t Mo = padd(Mc, o2);
+							const uint32_t Xo = pmax(pmax(Lc, Mc), Uc);
+							const uint32_t Ld = pmax(padd(Lc, e2), Mo);
+							if constexpr (TB) {
+								uint32_t nib = bfi(0x00030003u, Mraw, lraw);
+								nib = bfi(0x00070007u, nib, Uraw);
+								/* byte = [nibble of B | nibble of A] */
+								pbyte[r] = bfi(0xf0u, __builtin_amdgcn_alignbit(nib, nib, 12), nib);
+							}
+							if constexpr (MODE == K_LOCAL) {
+								const uint32_t key = (Mraw & keymask[r]) | rowtag[r];
+								cmax = r == 0 ? key : pmax(cmax, key);
+							}
+							diag = Xl[r];
+							Xl[r] = Xo;
+							lraw = Ld;
+							up = Xo;
+							Mo_l[r] = Mo; U_l[r] = Uc;
+							if constexpr (MODE != K_LOCAL) L_l[r] = Lc;
+						}
+						if constexpr (MODE == K_LOCAL) {
+							const uint32_t g = pneg(psub(best, cmax));   /* 0xffff where cmax > best */
+							bt = bfi(g, pk2(t), bt);
+							best = pmax(best, cmax);
+						}
+						A_prev = up; B_prev = lraw;
+						if (wb && lane == 63) mem.st2(a.off_bound + 2 * (jm1 + 1), up, lraw);
+					}
+					Ad = Aup;
+					if constexpr (TB) {
+#pragma unroll
+						for (int r = 0; r < K; ++r) acc[r] = __builtin_amdgcn_alignbit(pbyte[r], acc[r], 8);
+						if ((k & 3) == 3 && lane < NL) {
+#pragma unroll
+							for (int r = 0; r < K; ++r) mem.st(ptr_base + ((blk * 2 + hw) * K + r) * NL + lane, acc[r]);
+						}
+					}
+				};
+				using T = std::true_type;
+				using F = std::false_type;
+#define AT_STEPS16(M)                                                                                    \
+	step(std::integral_constant<int, 0>{}, M{}); step(std::integral_constant<int, 1>{}, M{});            \
+	step(std::integral_constant<int, 2>{}, M{}); step(std::integral_constant<int, 3>{}, M{});            \
+	step(std::integral_constant<int, 4>{}, M{}); step(std::integral_constant<int, 5>{}, M{});            \
+	step(std::integral_constant<int, 6>{}, M{}); step(std::integral_constant<int, 7>{}, M{});
+				if (t0 >= nl - 1 && t0 + kBlk <= l2) { AT_STEPS16(F) }
+				else { AT_STEPS16(T) }
+#undef AT_STEPS16
+				bx = bxn; bl = bln;
+			}
+			if constexpr (MODE == K_LOCAL) {
+				/* fold this strip's per-lane winner into the running one (earlier strips = smaller i win ties) */
+#pragma unroll
+				for (int h = 0; h < 2; ++h) {
+					const int key = half(best, h);
+					const int sc = key & ~15;
+					if (key != kNeg16 && sc > gbs[h]) {
+						gbs[h] = sc;
+						gbi[h] = i0 + (K - 1 - (key & 15)) + 1;
+						gbj[h] = (int)((bt >> (16 * h)) & 0xffffu) - lane + 1;
+					}
+				}
+			}
+			mem.sync();
+		}
+
+		/* ================= per pair: end cell, traceback, outputs ================= */
+#pragma unroll 1
+		for (int h = 0; h < 2; ++h) {
+			const long long p = h ? pB : pA;
+			if (h == 1 && pB == pA) break;
+			int sc16 = 0, ci = 0, cj = 0, st = 2;
+			bool ok = true;
+			if constexpr (MODE == K_LOCAL) {
+				int bs = gbs[h], bi = gbi[h], bj = gbj[h];
+				for (int d = 32; d >= 1; d >>= 1) {
+					const int ob = __shfl_xor(bs, d), oi = __shfl_xor(bi, d), oj = __shfl_xor(bj, d);
+					const bool take = ob > bs || (ob == bs && (oi < bi || (oi == bi && oj < bj)));
+					if (take) { bs = ob; bi = oi; bj = oj; }
+				}
+				sc16 = uni(bs); ci = uni(bi); cj = uni(bj); st = 2;
+			} else if constexpr (MODE == K_GLOBAL) {
+				const int eL = half((uint32_t)__builtin_amdgcn_readlane((int)pick<K>(L_l, rl), lastlane), h);
+				const int eM = half(psub((uint32_t)__builtin_amdgcn_readlane((int)pick<K>(Mo_l, rl), lastlane), pk2(o16)), h);
+				const int eU = half((uint32_t)__builtin_amdgcn_readlane((int)pick<K>(U_l, rl), lastlane), h);
+				const int x = imax3(eL, eM, eU);
+				sc16 = x; st = x & 3; ci = l1; cj = l2;
+			} else {
+				const int bM = half((uint32_t)__builtin_amdgcn_readlane((int)bestM, lastlane), h);
+				const int jM = half((uint32_t)__builtin_amdgcn_readlane((int)bestMj, lastlane), h);
+				const int bL = half((uint32_t)__builtin_amdgcn_readlane((int)bestL, lastlane), h);
+				const int jL = half((uint32_t)__builtin_amdgcn_readlane((int)bestLj, lastlane), h);
+				ci = l1;
+				if ((bL >> kShift) > (bM >> kShift) && bL > a.thresh16) { sc16 = bL; st = 3; cj = jL; }
+				else { sc16 = bM; st = 2; cj = jM; }
+				ok = sc16 > a.thresh16;
+			}
+			int cnt = 0;
+			const int ei = ci, ej = cj, est = st;
+			if constexpr (TB) {
+				uint8_t *ops = a.ops + a.ops_off[p];
+				uint32_t opreg = 0;
+				auto emit = [&](int op) {
+					if (lane == (cnt & 63)) opreg = (uint32_t)op;
+					if ((cnt & 63) == 63) ops[cnt - 63 + lane] = (uint8_t)opreg;
+					++cnt;
+				};
+				auto fetch = [&](int ii, int jj) -> uint32_t {
+					const int ss = (ii - 1) / RS, li = (ii - 1) % RS;
+					const int ln = li / K, r = li % K;
+					const int t = (jj - 1) + ln;
+					const uint32_t w = mem.ld(a.off_ptr + (ss * wps + (t >> 2) * K + r) * NL + ln);
+					return (uint32_t)uni((int)((w >> ((t & 3) * 8 + 4 * h)) & 15u));
+				};
+				int guard = l1 + l2 + 2;
+				if (ok) {
+					while (ci > 0 && (MODE == K_FIT || cj > 0) && --guard >= 0) {
+						if (MODE == K_LOCAL && st == 0) break;
+						if (cj <= 0) { ok = false; break; }
+						const uint32_t nb = fetch(ci, cj);
+						if (st == 3) { st = (nb & 4u) ? 3 : 2; emit(1); --ci; }
+						else if (st == 2) { st = (int)(nb & 3u); emit(0); --ci; --cj; }
+						else if (st == 1) { st = (nb & 8u) ? 2 : 1; emit(2); --cj; }
+						else { ok = false; break; }
+					}
+					if constexpr (MODE == K_GLOBAL) {
+						while (cj > 0) { emit(2); --cj; }
+						while (ci > 0) { emit(1); --ci; }
+					}
+					if (guard < 0) ok = false;
+				}
+				if ((cnt & 63) != 0 && lane < (cnt & 63)) ops[(cnt & ~63) + lane] = (uint8_t)opreg;
+			}
+			if (lane == 0) {
+				a.score[p] = ok ? (sc16 >> kShift) : INT32_MIN;
+				if (a.end_i) a.end_i[p] = ei;
+				if (a.end_j) a.end_j[p] = ej;
+				if (a.state) a.state[p] = est == 3 ? 1 : est == 2 ? 2 : 3;
+				if (a.nops) a.nops[p] = ok ? cnt : -1;
+			}
+		}
+		mem.sync();
+	}
+}
+
+} /* namespace at */

@@ -129,7 +129,7 @@ def main():
     def step(k):
         stream = torch.cuda.current_stream().cuda_stream
         al.align_batch_device(A.MODES[mode], pairs, d_words.data_ptr(), bits, d_woff1.data_ptr(), d_len1.data_ptr(),
-                              d_woff2.data_ptr(), d_len2.data_ptr(), l1, l2, tb,
+                              d_woff2.data_ptr(), d_len2.data_ptr(), l1, l2, True, tb,
                               d_res[0].data_ptr(), d_res[1].data_ptr(), d_res[2].data_ptr(), d_res[3].data_ptr(),
                               d_ops.data_ptr() if tb else None, d_ops_off.data_ptr() if tb else None,
                               d_nops.data_ptr() if tb else None, stream)

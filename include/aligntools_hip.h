@@ -100,12 +100,16 @@ int at_align_batch(at_handle *h, int mode, int64_t npairs,
  *              bits = 8 (4 bytes per int32, little endian)
  *   d_woff1/2  per pair WORD offset of s1 / s2 in d_seq
  *   max_len1/2 upper bounds of len1/len2 over the batch (sizes LDS / workspace)
+ *   uniform_shape  non-zero = the caller guarantees len1[k] == max_len1 and
+ *              len2[k] == max_len2 for every pair (fixed-length read batches);
+ *              enables the packed two-pairs-per-wavefront kernel when the
+ *              scores provably fit 16 bits.  0 is always safe.
  */
 int at_align_batch_device(at_handle *h, int mode, int64_t npairs,
                           const uint32_t *d_seq, int bits,
                           const int64_t *d_woff1, const int32_t *d_len1,
                           const int64_t *d_woff2, const int32_t *d_len2,
-                          int32_t max_len1, int32_t max_len2,
+                          int32_t max_len1, int32_t max_len2, int uniform_shape,
                           int want_traceback,
                           int32_t *d_score, int32_t *d_end_i, int32_t *d_end_j, int32_t *d_state,
                           uint8_t *d_ops, const int64_t *d_ops_off, int32_t *d_nops,

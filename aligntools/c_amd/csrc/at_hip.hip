@@ -29,6 +29,7 @@ struct at_handle {
 	/* device scratch (grow-only) */
 	uint32_t *d_sitemask = nullptr; size_t sitemask_words = 0; int sitemask_for_l2 = -1; bool sitemask_dirty = true;
 	uint32_t *d_ws = nullptr; size_t ws_bytes = 0;
+	unsigned long long *d_queue = nullptr;
 	void *d_in = nullptr; size_t in_bytes = 0;
 	void *d_out = nullptr; size_t out_bytes = 0;
 	char err[512] = {0};
@@ -93,6 +94,7 @@ extern "C" void at_destroy(at_handle *h)
 	(void)hipSetDevice(h->device);
 	if (h->d_sitemask) (void)hipFree(h->d_sitemask);
 	if (h->d_ws) (void)hipFree(h->d_ws);
+	if (h->d_queue) (void)hipFree(h->d_queue);
 	if (h->d_in) (void)hipFree(h->d_in);
 	if (h->d_out) (void)hipFree(h->d_out);
 	if (h->stream) (void)hipStreamDestroy(h->stream);
@@ -312,6 +314,66 @@ static long long env_ll(const char *name, long long dflt)
 	return v && *v ? atoll(v) : dflt;
 }
 
+
+/* Storage class + grid for one launch.
+ *   store 0  s2 window, boundary row and pointer matrix in LDS
+ *   store 1  s2 + boundary in LDS, pointer matrix in a per-wave global slot (HBM/L2)
+ *   store 2  everything in the global slot (very long s2)
+ * Work is handed out through an atomic counter, so the grid only has to cover the waves that
+ * can be resident; over-estimating it is harmless. */
+struct Plan {
+	int store, off_ptr;
+	long long grid, slot_words;
+	size_t dyn_lds;
+	uint32_t *ws;
+};
+
+static int plan_launch(at_handle *h, const char *tag, int k, long long nwork, long long words_fixed, long long words_ptr,
+                       Plan *pl, hipStream_t stream)
+{
+	/* all-LDS only while at least 8 waves (2 per SIMD) still fit a CU: measured, occupancy beyond 1 wave/SIMD is
+	 * worth +30..50 % on this issue-bound kernel (profiles/r01) */
+	const long long limit_all = env_ll("AT_SMALL_LDS_LIMIT", 20 * 1024);
+	const long long limit_fixed = env_ll("AT_MEDIUM_LDS_LIMIT", 64 * 1024);
+	const long long forced = env_ll("AT_STORE", -1);
+	int store;
+	if (forced >= 0 && forced <= 2) store = (int)forced;
+	else if ((words_fixed + words_ptr) * 4 <= limit_all) store = 0;
+	else if (words_fixed * 4 <= limit_fixed) store = 1;
+	else store = 2;
+	if (words_ptr == 0 && store == 1) store = 0;
+	if (store < 2 && words_fixed * 4 > 150 * 1024) store = 2;
+	if (store == 0 && (words_fixed + words_ptr) * 4 > 150 * 1024) store = 1;
+	const long long lds_words = store == 0 ? words_fixed + words_ptr : (store == 1 ? words_fixed : 0);
+	const long long slot_words = store == 0 ? 0 : (((store == 1 ? words_ptr : words_fixed + words_ptr) + 63) & ~63LL);
+	long long per_cu = 16;
+	if (lds_words > 0) per_cu = std::min<long long>(per_cu, (long long)(h->lds_per_cu - 512) / std::max<long long>(lds_words * 4, 256));
+	per_cu = std::max(1LL, std::min(per_cu, env_ll("AT_WAVES_PER_CU", 16)));
+	long long grid = std::max(1LL, std::min<long long>(nwork, per_cu * h->ncu));
+	pl->store = store;
+	pl->off_ptr = store == 1 ? 0 : (int)words_fixed;
+	pl->dyn_lds = (size_t)lds_words * 4;
+	pl->slot_words = slot_words;
+	pl->ws = nullptr;
+	if (slot_words > 0) {
+		const long long cap = env_ll("AT_WS_CAP_MB", 16384) << 20;
+		if (slot_words * 4 > cap) return fail(h, AT_ERR_NOMEM, "one pair needs %lld workspace bytes (cap %lld)", slot_words * 4, cap);
+		grid = std::max(1LL, std::min(grid, cap / (slot_words * 4)));
+		void *p = h->d_ws; size_t have = h->ws_bytes;
+		int rc = grow(h, &p, &have, (size_t)(grid * slot_words * 4));
+		h->d_ws = (uint32_t *)p; h->ws_bytes = have;
+		if (rc) return rc;
+		pl->ws = h->d_ws;
+	}
+	pl->grid = grid;
+	if (!h->d_queue) HIP_TRY(h, hipMalloc((void **)&h->d_queue, 64));
+	HIP_TRY(h, hipMemsetAsync(h->d_queue, 0, 8, stream));
+	static const char *names[3] = {"lds", "lds+hbm-pointers", "hbm"};
+	snprintf(h->cfg, sizeof h->cfg, "%s store=%s rows/lane=%d lds=%zuB slot=%lldB waves/cu<=%lld grid=%lld", tag, names[store], k,
+	         pl->dyn_lds, slot_words * 4, per_cu, grid);
+	return AT_OK;
+}
+
 extern "C" int at_align_batch_device(at_handle *h, int mode, int64_t npairs,
                                      const uint32_t *d_seq, int bits,
                                      const int64_t *d_woff1, const int32_t *d_len1,
@@ -347,9 +409,6 @@ extern "C" int at_align_batch_device(at_handle *h, int mode, int64_t npairs,
 	int thresh16 = 0;
 	if (uniform_shape && packed_ok(h, mode, bits, max_len1, max_len2, &thresh16)) {
 		const Layout16 P = layout16_for(tb, max_len1, max_len2);
-		const size_t lds16 = (size_t)P.words * 4;
-		const long long limit16 = env_ll("AT_SMALL_LDS_LIMIT", 40 * 1024);
-		const bool small16 = (long long)lds16 <= limit16 && !env_ll("AT_FORCE_LARGE", 0);
 		Sweep16Args b;
 		memset(&b, 0, sizeof b);
 		b.npairs = npairs; b.seq = d_seq;
@@ -358,43 +417,21 @@ extern "C" int at_align_batch_device(at_handle *h, int mode, int64_t npairs,
 		b.m16 = h->m * 16; b.u16 = h->u * 16; b.o16 = h->o * 16; b.e16 = h->e * 16; b.thresh16 = thresh16;
 		b.score = d_score; b.end_i = d_end_i; b.end_j = d_end_j; b.state = d_state;
 		b.ops = d_ops; b.ops_off = (const long long *)d_ops_off; b.nops = d_nops;
-		b.off_refb = P.off_refb; b.off_bound = P.off_bound; b.off_ptr = P.off_ptr; b.ptr_lanes = P.ptr_lanes;
-		const long long nwork = (npairs + 1) / 2;
-		long long grid16;
-		size_t dyn16 = 0;
-		if (small16) {
-			long long per_cu = (long long)((h->lds_per_cu - 1024) / std::max<size_t>(lds16, 512));
-			per_cu = std::max(1LL, std::min(per_cu, env_ll("AT_WAVES_PER_CU", 16)));
-			grid16 = std::min<long long>(nwork, per_cu * h->ncu);
-			dyn16 = lds16;
-			snprintf(h->cfg, sizeof h->cfg, "packed16 small(lds) rows/lane=%d lds=%zuB waves/cu=%lld grid=%lld (2 pairs/wave)", P.k, lds16, per_cu, grid16);
-		} else {
-			const long long per_cu = env_ll("AT_WAVES_PER_CU", 16);
-			const long long cap = env_ll("AT_WS_CAP_MB", 16384) << 20;
-			const long long slot_bytes = ((P.words + 63) & ~63LL) * 4;
-			grid16 = std::max(1LL, std::min(std::min<long long>(nwork, per_cu * h->ncu), cap / slot_bytes));
-			void *p = h->d_ws; size_t have = h->ws_bytes;
-			int rc = grow(h, &p, &have, (size_t)(grid16 * slot_bytes));
-			h->d_ws = (uint32_t *)p; h->ws_bytes = have;
-			if (rc) return rc;
-			b.ws = h->d_ws; b.ws_slot_words = slot_bytes / 4;
-			snprintf(h->cfg, sizeof h->cfg, "packed16 large(hbm) rows/lane=%d slot=%lldB grid=%lld (2 pairs/wave)", P.k, slot_bytes, grid16);
-		}
-		at_sweep16_fn fn16 = at_pick16(kmode, P.k, small16, tb);
-		if (dyn16 > 48 * 1024)
-			HIP_TRY(h, hipFuncSetAttribute((const void *)fn16, hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn16));
-		hipLaunchKernelGGL(fn16, dim3((unsigned)grid16), dim3(64), dyn16, stream, b);
+		b.off_refb = P.off_refb; b.off_bound = P.off_bound; b.ptr_lanes = P.ptr_lanes;
+		Plan pl;
+		int rc = plan_launch(h, "packed16", P.k, (npairs + 1) / 2, P.off_ptr, P.words - P.off_ptr, &pl, stream);
+		if (rc) return rc;
+		b.off_ptr = pl.off_ptr; b.ws = pl.ws; b.ws_slot_words = pl.slot_words; b.queue = h->d_queue;
+		at_sweep16_fn fn16 = at_pick16(kmode, P.k, pl.store, tb);
+		if (pl.dyn_lds > 48 * 1024)
+			HIP_TRY(h, hipFuncSetAttribute((const void *)fn16, hipFuncAttributeMaxDynamicSharedMemorySize, (int)pl.dyn_lds));
+		hipLaunchKernelGGL(fn16, dim3((unsigned)pl.grid), dim3(64), pl.dyn_lds, stream, b);
 		HIP_TRY(h, hipGetLastError());
 		return AT_OK;
 	}
 
 	const Layout L = layout_for(kmode, bits, tb, max_len1, max_len2);
 	if (L.words >= (1LL << 30)) return fail(h, AT_ERR_RANGE, "pair too large: %lld workspace words", L.words);
-
-	const long long small_limit = env_ll("AT_SMALL_LDS_LIMIT", 40 * 1024);
-	const size_t lds_bytes = (size_t)L.words * 4;
-	const bool small = (long long)lds_bytes <= small_limit && !env_ll("AT_FORCE_LARGE", 0);
-
 	SweepArgs a;
 	memset(&a, 0, sizeof a);
 	a.npairs = npairs;
@@ -405,40 +442,22 @@ extern "C" int at_align_batch_device(at_handle *h, int mode, int64_t npairs,
 	a.u_raw = h->u;
 	a.score = d_score; a.end_i = d_end_i; a.end_j = d_end_j; a.state = d_state;
 	a.ops = d_ops; a.ops_off = (const long long *)d_ops_off; a.nops = d_nops;
-	a.off_bound = L.off_bound; a.off_ptr = L.off_ptr; a.ptr_lanes = L.ptr_lanes;
+	a.off_bound = L.off_bound; a.ptr_lanes = L.ptr_lanes;
 	if (kmode == at::K_FITJ) {
 		int rc = ensure_sitemask(h, max_len2, stream);
 		if (rc) return rc;
 		a.sitemask = h->d_sitemask;
 	}
-
-	long long grid;
-	size_t dyn_lds = 0;
-	if (small) {
-		long long per_cu = (long long)((h->lds_per_cu - 1024) / std::max<size_t>(lds_bytes, 512));
-		per_cu = std::max(1LL, std::min(per_cu, env_ll("AT_WAVES_PER_CU", 16)));
-		grid = std::min<long long>(npairs, per_cu * h->ncu);
-		dyn_lds = lds_bytes;
-		snprintf(h->cfg, sizeof h->cfg, "small(lds) bits=%d rows/lane=%d lds=%zuB waves/cu=%lld grid=%lld", bits, L.k, lds_bytes, per_cu, grid);
-	} else {
-		long long per_cu = env_ll("AT_WAVES_PER_CU", 16);
-		grid = std::min<long long>(npairs, per_cu * h->ncu);
-		const long long cap = env_ll("AT_WS_CAP_MB", 16384) << 20;
-		const long long slot_bytes = ((L.words + 63) & ~63LL) * 4;
-		if (slot_bytes > cap) return fail(h, AT_ERR_NOMEM, "one pair needs %lld workspace bytes (cap %lld)", slot_bytes, cap);
-		grid = std::max(1LL, std::min(grid, cap / slot_bytes));
-		void *p = h->d_ws; size_t have = h->ws_bytes;
-		int rc = grow(h, &p, &have, (size_t)(grid * slot_bytes));
-		h->d_ws = (uint32_t *)p; h->ws_bytes = have;
-		if (rc) return rc;
-		a.ws = h->d_ws;
-		a.ws_slot_words = slot_bytes / 4;
-		snprintf(h->cfg, sizeof h->cfg, "large(hbm) bits=%d rows/lane=%d slot=%lldB grid=%lld", bits, L.k, slot_bytes, grid);
-	}
-	at_sweep_fn fn = bits == 2 ? at_pick32_b2(kmode, L.k, small, tb) : at_pick32_b8(kmode, L.k, small, tb);
-	if (dyn_lds > 48 * 1024)
-		HIP_TRY(h, hipFuncSetAttribute((const void *)fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn_lds));
-	hipLaunchKernelGGL(fn, dim3((unsigned)grid), dim3(64), dyn_lds, stream, a);
+	Plan pl;
+	char tag[32];
+	snprintf(tag, sizeof tag, "int32 bits=%d", bits);
+	int rc = plan_launch(h, tag, L.k, npairs, L.off_ptr, L.words - L.off_ptr, &pl, stream);
+	if (rc) return rc;
+	a.off_ptr = pl.off_ptr; a.ws = pl.ws; a.ws_slot_words = pl.slot_words; a.queue = h->d_queue;
+	at_sweep_fn fn = bits == 2 ? at_pick32_b2(kmode, L.k, pl.store, tb) : at_pick32_b8(kmode, L.k, pl.store, tb);
+	if (pl.dyn_lds > 48 * 1024)
+		HIP_TRY(h, hipFuncSetAttribute((const void *)fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)pl.dyn_lds));
+	hipLaunchKernelGGL(fn, dim3((unsigned)pl.grid), dim3(64), pl.dyn_lds, stream, a);
 	HIP_TRY(h, hipGetLastError());
 	return AT_OK;
 }

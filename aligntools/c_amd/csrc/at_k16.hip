@@ -1,25 +1,27 @@
 #include "at_launch.h"
 template <int MODE, int K>
-static at_sweep16_fn p3(bool small, bool tb)
+static at_sweep16_fn p3(int store, bool tb)
 {
-	if (small) return tb ? at::at_sweep16<MODE, K, true, true> : at::at_sweep16<MODE, K, true, false>;
-	return tb ? at::at_sweep16<MODE, K, false, true> : at::at_sweep16<MODE, K, false, false>;
+	if (!tb) return store < 2 ? at::at_sweep16<MODE, K, true, true, false> : at::at_sweep16<MODE, K, false, false, false>;
+	if (store == 0) return at::at_sweep16<MODE, K, true, true, true>;
+	if (store == 1) return at::at_sweep16<MODE, K, true, false, true>;
+	return at::at_sweep16<MODE, K, false, false, true>;
 }
 template <int MODE>
-static at_sweep16_fn p2(int k, bool small, bool tb)
+static at_sweep16_fn p2(int k, int store, bool tb)
 {
 	switch (k) {
-	case 1: return p3<MODE, 1>(small, tb);
-	case 2: return p3<MODE, 2>(small, tb);
-	case 3: return p3<MODE, 3>(small, tb);
-	default: return p3<MODE, 4>(small, tb);
+	case 1: return p3<MODE, 1>(store, tb);
+	case 2: return p3<MODE, 2>(store, tb);
+	case 3: return p3<MODE, 3>(store, tb);
+	default: return p3<MODE, 4>(store, tb);
 	}
 }
-at_sweep16_fn at_pick16(int kmode, int k, bool small, bool tb)
+at_sweep16_fn at_pick16(int kmode, int k, int store, bool tb)
 {
 	switch (kmode) {
-	case at::K_GLOBAL: return p2<at::K_GLOBAL>(k, small, tb);
-	case at::K_LOCAL: return p2<at::K_LOCAL>(k, small, tb);
-	default: return p2<at::K_FIT>(k, small, tb);
+	case at::K_GLOBAL: return p2<at::K_GLOBAL>(k, store, tb);
+	case at::K_LOCAL: return p2<at::K_LOCAL>(k, store, tb);
+	default: return p2<at::K_FIT>(k, store, tb);
 	}
 }

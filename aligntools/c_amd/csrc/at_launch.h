@@ -6,39 +6,42 @@
 typedef void (*at_sweep_fn)(const at::SweepArgs);
 typedef void (*at_sweep16_fn)(const at::Sweep16Args);
 
-at_sweep_fn at_pick32_b2(int kmode, int k, bool small, bool tb);
-at_sweep_fn at_pick32_b8(int kmode, int k, bool small, bool tb);
-at_sweep16_fn at_pick16(int kmode, int k, bool small, bool tb);   /* kmode in {K_GLOBAL, K_LOCAL, K_FIT} */
+/* store: 0 = everything in LDS, 1 = s2/boundary in LDS + pointers in the global slot, 2 = everything global */
+at_sweep_fn at_pick32_b2(int kmode, int k, int store, bool tb);
+at_sweep_fn at_pick32_b8(int kmode, int k, int store, bool tb);
+at_sweep16_fn at_pick16(int kmode, int k, int store, bool tb);   /* kmode in {K_GLOBAL, K_LOCAL, K_FIT} */
 
 template <int MODE, int BITS, int K>
-static at_sweep_fn at_pick3(bool small, bool tb)
+static at_sweep_fn at_pick3(int store, bool tb)
 {
 	if constexpr (MODE == at::K_EDIT) {
-		return small ? at::at_sweep<MODE, BITS, K, true, false> : at::at_sweep<MODE, BITS, K, false, false>;
+		return store < 2 ? at::at_sweep<MODE, BITS, K, true, true, false> : at::at_sweep<MODE, BITS, K, false, false, false>;
 	} else {
-		if (small) return tb ? at::at_sweep<MODE, BITS, K, true, true> : at::at_sweep<MODE, BITS, K, true, false>;
-		return tb ? at::at_sweep<MODE, BITS, K, false, true> : at::at_sweep<MODE, BITS, K, false, false>;
+		if (!tb) return store < 2 ? at::at_sweep<MODE, BITS, K, true, true, false> : at::at_sweep<MODE, BITS, K, false, false, false>;
+		if (store == 0) return at::at_sweep<MODE, BITS, K, true, true, true>;
+		if (store == 1) return at::at_sweep<MODE, BITS, K, true, false, true>;
+		return at::at_sweep<MODE, BITS, K, false, false, true>;
 	}
 }
 template <int MODE, int BITS>
-static at_sweep_fn at_pick2(int k, bool small, bool tb)
+static at_sweep_fn at_pick2(int k, int store, bool tb)
 {
 	switch (k) {
-	case 1: return at_pick3<MODE, BITS, 1>(small, tb);
-	case 2: return at_pick3<MODE, BITS, 2>(small, tb);
-	case 3: return at_pick3<MODE, BITS, 3>(small, tb);
-	default: return at_pick3<MODE, BITS, 4>(small, tb);
+	case 1: return at_pick3<MODE, BITS, 1>(store, tb);
+	case 2: return at_pick3<MODE, BITS, 2>(store, tb);
+	case 3: return at_pick3<MODE, BITS, 3>(store, tb);
+	default: return at_pick3<MODE, BITS, 4>(store, tb);
 	}
 }
 template <int BITS>
-static at_sweep_fn at_pick1(int kmode, int k, bool small, bool tb)
+static at_sweep_fn at_pick1(int kmode, int k, int store, bool tb)
 {
 	switch (kmode) {
-	case at::K_GLOBAL: return at_pick2<at::K_GLOBAL, BITS>(k, small, tb);
-	case at::K_LOCAL: return at_pick2<at::K_LOCAL, BITS>(k, small, tb);
-	case at::K_FIT: return at_pick2<at::K_FIT, BITS>(k, small, tb);
-	case at::K_FITJ: return at_pick2<at::K_FITJ, BITS>(k, small, tb);
-	case at::K_OVERLAP: return at_pick2<at::K_OVERLAP, BITS>(k, small, tb);
-	default: return at_pick2<at::K_EDIT, BITS>(k, small, tb);
+	case at::K_GLOBAL: return at_pick2<at::K_GLOBAL, BITS>(k, store, tb);
+	case at::K_LOCAL: return at_pick2<at::K_LOCAL, BITS>(k, store, tb);
+	case at::K_FIT: return at_pick2<at::K_FIT, BITS>(k, store, tb);
+	case at::K_FITJ: return at_pick2<at::K_FITJ, BITS>(k, store, tb);
+	case at::K_OVERLAP: return at_pick2<at::K_OVERLAP, BITS>(k, store, tb);
+	default: return at_pick2<at::K_EDIT, BITS>(k, store, tb);
 	}
 }

@@ -76,6 +76,7 @@ struct SweepArgs {
 	long long ws_slot_words;
 	int off_bound, off_ptr;        /* word offsets of the regions inside a slot    */
 	int ptr_lanes;                 /* lanes per pointer row (min(64, ceil(max_l1/K))) */
+	unsigned long long *queue;     /* work counter, zeroed before every launch     */
 };
 
 extern __shared__ uint32_t at_lds[];
@@ -137,6 +138,37 @@ struct Slot {
 	}
 };
 
+/* The pointer matrix: LDS, or a per-wave global slot (stores are fire-and-forget coalesced rows;
+ * the traceback reads them back L2-served after the wave's stores have been acknowledged). */
+template <bool LDS>
+struct PtrStore {
+	uint32_t *g;
+	AT_DEV void st(int i, uint32_t v) const
+	{
+		if constexpr (LDS) at_lds[i] = v;
+		else g[i] = v;
+	}
+	AT_DEV uint32_t ld(int i) const
+	{
+		if constexpr (LDS) return at_lds[i];
+		else return __hip_atomic_load(g + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   /* sc1: bypasses this CU's L1 */
+	}
+	AT_DEV void ready() const   /* before the first ld of a pair */
+	{
+		if constexpr (LDS) __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+		else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+	}
+};
+
+/* Dynamic work distribution: one returning atomic per work item, issued one item ahead. */
+AT_DEV long long next_work(unsigned long long *queue, int lane)
+{
+	unsigned long long v = 0;
+	if (lane == 0) v = atomicAdd(queue, 1ull);
+	return (long long)(((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(v >> 32)) << 32) |
+	                   (unsigned)__builtin_amdgcn_readfirstlane((int)v));
+}
+
 /* Border cells (i == 0 or j == 0), scaled, untagged.
  * global  alignment.h:428-441 | local: calloc zeros
  * fit     alignment.h:612-624 (row 0 written after column 0, so (0,0) is a row-0 cell) */
@@ -174,7 +206,7 @@ AT_DEV int pick(const int (&v)[K], int r)   /* r is wave-uniform */
 	return x;
 }
 
-template <int MODE, int BITS, int K, bool SMALL, bool TB>
+template <int MODE, int BITS, int K, bool SMALL, bool PTRLDS, bool TB>
 __global__ __launch_bounds__(64) void at_sweep(const SweepArgs a)
 {
 	constexpr bool AFFINE = MODE <= K_FITJ;
@@ -191,6 +223,8 @@ __global__ __launch_bounds__(64) void at_sweep(const SweepArgs a)
 	const int lane = threadIdx.x;
 	Slot<SMALL> mem;
 	mem.g = SMALL ? nullptr : a.ws + (long long)blockIdx.x * a.ws_slot_words;
+	PtrStore<PTRLDS> pm;
+	pm.g = PTRLDS ? nullptr : a.ws + (long long)blockIdx.x * a.ws_slot_words;
 	const int m16 = a.m16, u16 = a.u16, o16 = a.o16, e16 = a.e16, g16 = a.g16;
 	const int NL = a.ptr_lanes;
 	/* keep the mismatch score in a VGPR the compiler will not re-materialise per step */
@@ -198,7 +232,10 @@ __global__ __launch_bounds__(64) void at_sweep(const SweepArgs a)
 	asm volatile("" : "+v"(u16v));
 	const int m16s = MODE == K_EDIT ? 0 : (MODE == K_OVERLAP ? m16 - o16 : m16);
 
-	for (long long p = blockIdx.x; p < a.npairs; p += gridDim.x) {
+	long long pnext = next_work(a.queue, lane);
+	while (pnext < a.npairs) {
+		const long long p = pnext;
+		pnext = next_work(a.queue, lane);   /* consumed at the end of this pair: latency hidden */
 		const int l1 = uni(a.len1[p]);
 		const int l2 = uni(a.len2[p]);
 		const uint32_t *q_words = a.seq + a.woff1[p];
@@ -414,7 +451,7 @@ __global__ __launch_bounds__(64) void at_sweep(const SweepArgs a)
 							if ((k + 1) % SPD == 0 && lane < NL) {
 #pragma unroll
 								for (int r = 0; r < K; ++r)
-									mem.st(ptr_base + ((blk * RPB + k / SPD) * K + r) * NL + lane, acc[r]);
+									pm.st(ptr_base + ((blk * RPB + k / SPD) * K + r) * NL + lane, acc[r]);
 							}
 						}
 					}
@@ -434,7 +471,7 @@ __global__ __launch_bounds__(64) void at_sweep(const SweepArgs a)
 				if constexpr (TB && SPD == kBlk) {
 					if (lane < NL) {
 #pragma unroll
-						for (int r = 0; r < K; ++r) mem.st(ptr_base + (blk * K + r) * NL + lane, acc[r]);
+						for (int r = 0; r < K; ++r) pm.st(ptr_base + (blk * K + r) * NL + lane, acc[r]);
 					}
 				}
 				bx = bxn; bl = bln;
@@ -511,10 +548,11 @@ __global__ __launch_bounds__(64) void at_sweep(const SweepArgs a)
 				const int ss = (ii - 1) / RS, li = (ii - 1) % RS;
 				const int ln = li / K, r = li % K;
 				const int t = (jj - 1) + ln;
-				const uint32_t w = mem.ld(a.off_ptr + (ss * wps + (t / SPD) * K + r) * NL + ln);
+				const uint32_t w = pm.ld(a.off_ptr + (ss * wps + (t / SPD) * K + r) * NL + ln);
 				return (uint32_t)uni((int)((w >> ((t % SPD) * PB)) & ((1u << PB) - 1u)));
 			};
 			int guard = l1 + l2 + 2;
+			pm.ready();
 			if (ok) {
 				if constexpr (AFFINE) {
 					/* trace_back_gla :377-397, _local_affine :771-795, _fit_affine_jump :562-587 */

@@ -46,6 +46,7 @@ struct Sweep16Args {
 	long long ws_slot_words;
 	int off_refb, off_bound, off_ptr;
 	int ptr_lanes;
+	unsigned long long *queue;     /* work counter, zeroed before every launch */
 };
 
 AT_DEV uint32_t pk2(int v) { return ((uint32_t)v & 0xffffu) | ((uint32_t)v << 16); }
@@ -65,6 +66,19 @@ AT_DEV uint32_t pmax(uint32_t a, uint32_t b)
 AT_DEV uint32_t pneg(uint32_t a)
 {
 	return __builtin_bit_cast(uint32_t, __builtin_bit_cast(s16x2, a) >> (s16x2)(15));
+}
+/* v_bfi_b32 / v_and_or_b32 spelled out: hipcc otherwise re-associates the nested selects into longer and/or3 chains */
+AT_DEV uint32_t vbfi(uint32_t mask, uint32_t a, uint32_t b)
+{
+	uint32_t d;
+	asm("v_bfi_b32 %0, %1, %2, %3" : "=v"(d) : "v"(mask), "v"(a), "v"(b));
+	return d;
+}
+AT_DEV uint32_t vandor(uint32_t a, uint32_t m, uint32_t o)
+{
+	uint32_t d;
+	asm("v_and_or_b32 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(m), "v"(o));
+	return d;
 }
 AT_DEV int half(uint32_t v, int h) { return (int)(short)(h ? (v >> 16) : (v & 0xffffu)); }
 
@@ -98,7 +112,7 @@ AT_DEV uint32_t pick(const uint32_t (&v)[K], int r)
 	return x;
 }
 
-template <int MODE, int K, bool SMALL, bool TB>
+template <int MODE, int K, bool SMALL, bool PTRLDS, bool TB>
 __global__ __launch_bounds__(64) void at_sweep16(const Sweep16Args a)
 {
 	static_assert(MODE == K_GLOBAL || MODE == K_LOCAL || MODE == K_FIT, "packed path: 3-state modes without the jump state");
@@ -107,13 +121,19 @@ __global__ __launch_bounds__(64) void at_sweep16(const Sweep16Args a)
 	const int lane = threadIdx.x;
 	Slot<SMALL> mem;
 	mem.g = SMALL ? nullptr : a.ws + (long long)blockIdx.x * a.ws_slot_words;
+	PtrStore<PTRLDS> pm;
+	pm.g = PTRLDS ? nullptr : a.ws + (long long)blockIdx.x * a.ws_slot_words;
 	const int l1 = a.l1, l2 = a.l2, NL = a.ptr_lanes;
 	const int o16 = a.o16, e16 = a.e16;
 	uint32_t o2 = pk2(a.o16), e2 = pk2(a.e16);
 	/* byte LUT for v_perm: pool bytes 0..3 = low bytes of {m,u,u,u}, 4..7 = high bytes */
 	uint32_t lut_lo = ((uint32_t)a.m16 & 0xffu) | (((uint32_t)a.u16 & 0xffu) * 0x01010100u);
 	uint32_t lut_hi = (((uint32_t)a.m16 >> 8) & 0xffu) | ((((uint32_t)a.u16 >> 8) & 0xffu) * 0x01010100u);
+	/* constants live in VGPRs: VOP3 encodings take no 32-bit literals, and a literal would split and_or into two ops */
+	uint32_t cClean = kClean2, cTagM = kTagM2, cTagL = kTagL2, cTagU = kTagU2, c04 = 0x04000400u;
+	uint32_t cM3 = 0x00030003u, cM7 = 0x00070007u, cF0 = 0xf0u;
 	asm volatile("" : "+v"(o2), "+v"(e2), "+v"(lut_lo), "+v"(lut_hi));
+	asm volatile("" : "+v"(cClean), "+v"(cTagM), "+v"(cTagL), "+v"(cTagU), "+v"(c04), "+v"(cM3), "+v"(cM7), "+v"(cF0));
 	const int nstrips = (l1 + RS - 1) / RS;
 	const int tbk = (l2 + 63 + kBlk - 1) / kBlk;
 	const int wps = tbk * 2 * K;              /* pointer word rows per strip: 4 steps per word */
@@ -121,7 +141,10 @@ __global__ __launch_bounds__(64) void at_sweep16(const Sweep16Args a)
 	const int rl = l1 > 0 ? ((l1 - 1) % RS) % K : 0;
 	const long long nwork = (a.npairs + 1) >> 1;
 
-	for (long long wk = blockIdx.x; wk < nwork; wk += gridDim.x) {
+	long long wnext = next_work(a.queue, lane);
+	while (wnext < nwork) {
+		const long long wk = wnext;
+		wnext = next_work(a.queue, lane);   /* consumed at the end of this work item: latency hidden */
 		const long long pA = 2 * wk;
 		const long long pB = (2 * wk + 1 < a.npairs) ? 2 * wk + 1 : pA;
 		const uint32_t *qA = a.seq + a.woff1[pA], *qB = a.seq + a.woff1[pB];
@@ -224,6 +247,8 @@ __global__ __launch_bounds__(64) void at_sweep16(const Sweep16Args a)
 					/* selector picking byte kk of xA (pool 0..3) twice and of xB (pool 4..7) twice */
 					constexpr uint32_t SELK = (uint32_t)kk * 0x00000101u + (uint32_t)(4 + kk) * 0x01010000u;
 					const int t = t0 + k;
+					uint32_t tpk = pk2(t);
+					asm("" : "+v"(tpk));
 					const uint32_t Aup = (uint32_t)shfl_up1((int)row_shl<k>((int)bx), (int)A_prev);
 					const uint32_t Bup = (uint32_t)shfl_up1((int)row_shl<k>((int)bl), (int)B_prev);
 					const int jm1 = jm1_0 + k;
@@ -249,25 +274,25 @@ __global__ __launch_bounds__(64) void at_sweep16(const Sweep16Args a)
 						uint32_t diag = Ad, lraw = Bup, up = 0, cmax = 0;
 #pragma unroll
 						for (int r = 0; r < K; ++r) {
-							uint32_t sel = __builtin_amdgcn_perm(xB[hw][r], xA[hw][r], SELK) | 0x04000400u;
+							const uint32_t sel = __builtin_amdgcn_perm(xB[hw][r], xA[hw][r], SELK) | c04;
 							const uint32_t S = __builtin_amdgcn_perm(lut_hi, lut_lo, sel);
 							uint32_t Mraw = padd(diag, S);
 							if constexpr (MODE == K_LOCAL) Mraw = pmax(Mraw, 0u);
-							const uint32_t Mc = (Mraw & kClean2) | kTagM2;
-							const uint32_t Lc = lraw | kTagL2;
+							const uint32_t Mc = vandor(Mraw, cClean, cTagM);
+							const uint32_t Lc = lraw | cTagL;
 							const uint32_t Uraw = pmax(Mo_l[r], padd(U_l[r], e2));
-							const uint32_t Uc = (Uraw & kClean2) | kTagU2;
+							const uint32_t Uc = vandor(Uraw, cClean, cTagU);
 							const uint32_t Mo = padd(Mc, o2);
 							const uint32_t Xo = pmax(pmax(Lc, Mc), Uc);
 							const uint32_t Ld = pmax(padd(Lc, e2), Mo);
 							if constexpr (TB) {
-								uint32_t nib = bfi(0x00030003u, Mraw, lraw);
-								nib = bfi(0x00070007u, nib, Uraw);
+								uint32_t nib = vbfi(cM3, Mraw, lraw);
+								nib = vbfi(cM7, nib, Uraw);
 								/* byte = [nibble of B | nibble of A] */
-								pbyte[r] = bfi(0xf0u, __builtin_amdgcn_alignbit(nib, nib, 12), nib);
+								pbyte[r] = vbfi(cF0, __builtin_amdgcn_alignbit(nib, nib, 12), nib);
 							}
 							if constexpr (MODE == K_LOCAL) {
-								const uint32_t key = (Mraw & keymask[r]) | rowtag[r];
+								const uint32_t key = vandor(Mraw, keymask[r], rowtag[r]);
 								cmax = r == 0 ? key : pmax(cmax, key);
 							}
 							diag = Xl[r];
@@ -278,8 +303,10 @@ __global__ __launch_bounds__(64) void at_sweep16(const Sweep16Args a)
 							if constexpr (MODE != K_LOCAL) L_l[r] = Lc;
 						}
 						if constexpr (MODE == K_LOCAL) {
-							const uint32_t g = pneg(psub(best, cmax));   /* 0xffff where cmax > best */
-							bt = bfi(g, pk2(t), bt);
+							uint32_t dlt = psub(best, cmax);
+							asm("" : "+v"(dlt));                        /* keep hipcc from turning this into 2 cmp + 2 cndmask + perm */
+							const uint32_t g = pneg(dlt);               /* 0xffff where cmax > best */
+							bt = vbfi(g, tpk, bt);
 							best = pmax(best, cmax);
 						}
 						A_prev = up; B_prev = lraw;
@@ -291,7 +318,7 @@ __global__ __launch_bounds__(64) void at_sweep16(const Sweep16Args a)
 						for (int r = 0; r < K; ++r) acc[r] = __builtin_amdgcn_alignbit(pbyte[r], acc[r], 8);
 						if ((k & 3) == 3 && lane < NL) {
 #pragma unroll
-							for (int r = 0; r < K; ++r) mem.st(ptr_base + ((blk * 2 + hw) * K + r) * NL + lane, acc[r]);
+							for (int r = 0; r < K; ++r) pm.st(ptr_base + ((blk * 2 + hw) * K + r) * NL + lane, acc[r]);
 						}
 					}
 				};
@@ -323,6 +350,7 @@ __global__ __launch_bounds__(64) void at_sweep16(const Sweep16Args a)
 			mem.sync();
 		}
 
+		pm.ready();
 		/* ================= per pair: end cell, traceback, outputs ================= */
 #pragma unroll 1
 		for (int h = 0; h < 2; ++h) {
@@ -368,7 +396,7 @@ __global__ __launch_bounds__(64) void at_sweep16(const Sweep16Args a)
 					const int ss = (ii - 1) / RS, li = (ii - 1) % RS;
 					const int ln = li / K, r = li % K;
 					const int t = (jj - 1) + ln;
-					const uint32_t w = mem.ld(a.off_ptr + (ss * wps + (t >> 2) * K + r) * NL + ln);
+					const uint32_t w = pm.ld(a.off_ptr + (ss * wps + (t >> 2) * K + r) * NL + ln);
 					return (uint32_t)uni((int)((w >> ((t & 3) * 8 + 4 * h)) & 15u));
 				};
 				int guard = l1 + l2 + 2;

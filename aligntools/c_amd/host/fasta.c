@@ -1,0 +1,160 @@
+/*
+ * fasta.c -- gz FASTA/FASTQ reader of the C host.
+ *
+ * Own implementation with the record semantics of the reference's input path
+ * (kstring_read, alignment.h:217-262, over klib's kseq_read, kseq.h:189-229):
+ *   - skip to the first '>' or '@';
+ *   - name = header up to the first whitespace, comment = rest of the header
+ *     line (a trailing '\r' is dropped);
+ *   - sequence = all following lines (empty lines skipped, '\r' stripped) up to
+ *     a line starting with '>', '@' or '+';
+ *   - '+' starts a FASTQ quality block: as many quality lines as needed to
+ *     cover the sequence are skipped; a truncated block ends the file;
+ *   - kseq keeps ONE comment buffer for the whole file, and kstring_read copies
+ *     it whenever it is non-NULL (alignment.h:235) -- so a record without a
+ *     comment inherits the text of the last record that had one.  Reproduced.
+ * Plain and gzip input are both read through zlib's gzread.
+ */
+#define _POSIX_C_SOURCE 200809L
+#include "at_host.h"
+#include <ctype.h>
+#include <stdlib.h>
+#include <string.h>
+#include <zlib.h>
+
+typedef struct {
+	gzFile f;
+	unsigned char buf[16384];
+	int begin, end, eof;
+} stream;
+
+static int sgetc(stream *s)
+{
+	if (s->eof && s->begin >= s->end) return -1;
+	if (s->begin >= s->end) {
+		s->begin = 0;
+		s->end = gzread(s->f, s->buf, sizeof s->buf);
+		if (s->end <= 0) { s->end = 0; s->eof = 1; return -1; }
+	}
+	return s->buf[s->begin++];
+}
+
+typedef struct {
+	char *s;
+	size_t l, m;
+} sbuf;
+
+static void sput(sbuf *b, int c)
+{
+	if (b->l + 2 > b->m) {
+		b->m = b->m ? b->m * 2 : 256;
+		b->s = (char *)realloc(b->s, b->m);
+		if (!b->s) die("mycalloc failure requesting %d of size %d bytes", (int)b->m, 1);
+	}
+	b->s[b->l++] = (char)c;
+	b->s[b->l] = 0;
+}
+
+/* read up to '\n' (line == 1) or any whitespace (line == 0); returns the delimiter or -1 at EOF,
+ * *got = whether anything (even an empty field) was consumed */
+static int sgetuntil(stream *s, int line, sbuf *b, int append, int *got)
+{
+	int c;
+	*got = 0;
+	if (!append) { b->l = 0; if (b->s) b->s[0] = 0; }
+	for (;;) {
+		c = sgetc(s);
+		if (c < 0) break;
+		*got = 1;
+		if (line ? c == '\n' : isspace(c)) break;
+		sput(b, c);
+	}
+	if (!b->s) sput(b, 0), b->l = 0;
+	if (line && b->l > 1 && b->s[b->l - 1] == '\r') b->s[--b->l] = 0;
+	return c;
+}
+
+int at_read_records(const char *fname, at_records *out)
+{
+	stream *st;
+	sbuf name = {0, 0, 0}, comment = {0, 0, 0}, seq = {0, 0, 0}, qual = {0, 0, 0};
+	int c, last = 0, got;
+	size_t cap = 0;
+	memset(out, 0, sizeof *out);
+	st = (stream *)calloc(1, sizeof *st);
+	if (!st) return -1;
+	st->f = gzopen(fname, "r");
+	if (!st->f) { free(st); return -1; }
+	for (;;) {
+		if (last == 0) {
+			while ((c = sgetc(st)) != -1 && c != '>' && c != '@') {}
+			if (c == -1) break;
+			last = c;
+		}
+		seq.l = 0;
+		c = sgetuntil(st, 0, &name, 0, &got);
+		if (!got && c < 0) break;
+		if (c != '\n' && c >= 0) sgetuntil(st, 1, &comment, 0, &got);
+		while ((c = sgetc(st)) != -1 && c != '>' && c != '+' && c != '@') {
+			if (c == '\n') continue;
+			sput(&seq, c);
+			sgetuntil(st, 1, &seq, 1, &got);
+		}
+		last = (c == '>' || c == '@') ? c : 0;
+		if (c == '+') {
+			while ((c = sgetc(st)) != -1 && c != '\n') {}
+			if (c == -1) break;                     /* no quality string: kseq_read returns -2 */
+			qual.l = 0;
+			for (;;) {
+				int d = sgetuntil(st, 1, &qual, 1, &got);
+				if ((!got && d < 0) || qual.l >= seq.l) break;
+			}
+			last = 0;
+			if (qual.l != seq.l) break;            /* truncated quality: -2 ends the reader loop */
+		}
+		if (out->n == cap) {
+			cap = cap ? cap * 2 : 4;
+			out->name = (char **)realloc(out->name, cap * sizeof(char *));
+			out->comment = (char **)realloc(out->comment, cap * sizeof(char *));
+			out->seq = (char **)realloc(out->seq, cap * sizeof(char *));
+			out->len = (size_t *)realloc(out->len, cap * sizeof(size_t));
+		}
+		out->name[out->n] = strdup(name.s ? name.s : "");
+		out->comment[out->n] = comment.s ? strdup(comment.s) : NULL;   /* the shared-buffer quirk */
+		out->seq[out->n] = (char *)malloc(seq.l + 1);
+		memcpy(out->seq[out->n], seq.s ? seq.s : "", seq.l);
+		out->seq[out->n][seq.l] = 0;
+		out->len[out->n] = seq.l;
+		out->n++;
+	}
+	free(name.s); free(comment.s); free(seq.s); free(qual.s);
+	gzclose(st->f);
+	free(st);
+	return 0;
+}
+
+void at_free_records(at_records *r)
+{
+	size_t k;
+	for (k = 0; k < r->n; ++k) { free(r->name[k]); free(r->comment[k]); free(r->seq[k]); }
+	free(r->name); free(r->comment); free(r->seq); free(r->len);
+	memset(r, 0, sizeof *r);
+}
+
+/* ksplit(tmp, '|', &n) + atoi per field (alignment.h:250-253, kstring.c:89-131): fields are the
+ * maximal runs of non-'|' characters */
+int at_parse_sites(const char *comment, int **pos_out)
+{
+	size_t l = strlen(comment), i, cap = 8;
+	int n = 0, *pos = (int *)calloc(cap, sizeof(int));
+	i = 0;
+	while (i < l) {
+		while (i < l && comment[i] == '|') ++i;
+		if (i >= l) break;
+		if ((size_t)n == cap) { cap *= 2; pos = (int *)realloc(pos, cap * sizeof(int)); }
+		pos[n++] = atoi(comment + i);
+		while (i < l && comment[i] != '|') ++i;
+	}
+	*pos_out = pos;
+	return n;
+}

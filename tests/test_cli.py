@@ -1,0 +1,143 @@
+"""The C host: `alignTools <cmd> [opts] <target.fa>` byte-for-byte against what the stock
+reference CLI printed (tests/golden/cli.jsonl: stdout, stderr, return code), and the
+gz-FASTA reader against the record semantics of the reference's kstring_read/kseq_read.
+Error paths run anywhere; commands that align need the GPU (-m gpu)."""
+import ctypes as C
+import gzip
+import hashlib
+import os
+import subprocess
+
+import pytest
+
+from conftest import ROOT, load_golden
+
+EXE = os.path.join(ROOT, "aligntools", "c_amd", "bin", "alignTools")
+HOSTLIB = os.path.join(ROOT, "aligntools", "c_amd", "libaligntools.so")
+
+
+@pytest.fixture(scope="module")
+def built():
+    from aligntools.c_amd import build
+    build.build()
+    assert os.path.exists(EXE)
+    return EXE
+
+
+@pytest.fixture(scope="module")
+def ref_inputs(tmp_path_factory):
+    """The reference's test/*.fa inputs, re-created from the golden fixtures (sequences + site comment)."""
+    d = tmp_path_factory.mktemp("cli")
+    os.makedirs(d / "test")
+    seen = {}
+    for c in load_golden("known_answers.jsonl"):
+        tag = c["tag"].split(" ")[0]
+        if tag in seen:
+            continue
+        seen[tag] = (c["s1"], c["s2"])
+    comment = {"test_fit": " 1036|3395|23045|24611"}
+    for tag, (s1, s2) in seen.items():
+        with open(d / "test" / (tag + ".fa"), "w") as fh:
+            fh.write(">first\n")
+            for k in range(0, len(s1), 70):
+                fh.write(s1[k:k + 70] + "\n")
+            fh.write(">second%s\n%s\n" % (comment.get(tag, ""), s2))
+    return d
+
+
+def _run(argv, cwd):
+    p = subprocess.run([EXE] + argv, cwd=cwd, capture_output=True)
+    return p.returncode, p.stdout.decode("latin1"), p.stderr.decode("latin1").replace(EXE, "alignTools")
+
+
+def _cases(need_gpu):
+    out = []
+    for c in load_golden("cli.jsonl"):
+        aligns = c["rc"] == 0 or c["argv"][:1] == ["fit"] and c["argv"][-1].endswith("test_global.fa")
+        if aligns == need_gpu:
+            out.append(c)
+    return out
+
+
+@pytest.mark.parametrize("case", _cases(False), ids=lambda c: " ".join(c["argv"]) or "noargs")
+def test_cli_error_paths_match_reference(built, ref_inputs, case):
+    rc, so, se = _run(case["argv"], ref_inputs)
+    assert rc == case["rc"]
+    assert so == case.get("stdout", "")
+    assert se == case["stderr"]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("case", _cases(True), ids=lambda c: " ".join(c["argv"]))
+def test_cli_outputs_match_reference(built, ref_inputs, case):
+    rc, so, se = _run(case["argv"], ref_inputs)
+    assert rc == case["rc"], se
+    if "stdout" in case:
+        assert so == case["stdout"]
+    else:
+        assert len(so) == case["stdout_len"] and hashlib.md5(so.encode("latin1")).hexdigest() == case["stdout_md5"]
+    assert se == case["stderr"]
+
+
+@pytest.mark.gpu
+def test_cli_edit_rejects_dash_e_instead_of_crashing(built, ref_inputs):
+    """The reference declares `-e` without an argument for `edit` and calls atoi(NULL) (SIGSEGV); we return 1."""
+    rc, so, se = _run(["edit", "-e", "test/test_edit.fa"], ref_inputs)
+    assert rc == 1 and so == ""
+
+
+@pytest.mark.gpu
+def test_cli_batch_extension(built, tmp_path):
+    with open(tmp_path / "pairs.fa", "w") as fh:
+        fh.write(">a1\nPLEASANTLY\n>a2\nMEANLY\n>b1\nACGTACGT\n>b2\nACGTTACGT\n")
+    p = subprocess.run([EXE, "batch", "local", "-m", "2", "-u", "-2", "-o", "-5", "-e", "-2", "pairs.fa"], cwd=tmp_path,
+                       capture_output=True)
+    assert p.returncode == 0, p.stderr
+    lines = p.stdout.decode().splitlines()
+    assert lines[0] == "a1\ta2\tscore=4.000000" and lines[1:3] == ["LEA", "MEA"]
+    assert lines[3].startswith("b1\tb2\tscore=")
+
+
+# ---------------------------------------------------------------- FASTA reader (CPU)
+class _Records(C.Structure):
+    _fields_ = [("n", C.c_size_t), ("name", C.POINTER(C.c_char_p)), ("comment", C.POINTER(C.c_char_p)),
+                ("seq", C.POINTER(C.c_char_p)), ("len", C.POINTER(C.c_size_t))]
+
+
+def _read(path):
+    lib = C.CDLL(HOSTLIB)
+    lib.at_read_records.argtypes = [C.c_char_p, C.POINTER(_Records)]
+    lib.at_free_records.argtypes = [C.POINTER(_Records)]
+    r = _Records()
+    rc = lib.at_read_records(str(path).encode(), C.byref(r))
+    if rc:
+        return None
+    out = [(r.name[k].decode(), None if not r.comment[k] else r.comment[k].decode(), r.seq[k].decode()) for k in range(r.n)]
+    lib.at_free_records(C.byref(r))
+    return out
+
+
+def test_reader_semantics(built, tmp_path):
+    p = tmp_path / "a.fa"
+    p.write_bytes(b"junk before\n>r1 first comment\r\nACGT\r\nAC\r\n\n>r2\nTTTT\nGG\n")
+    assert _read(p) == [("r1", "first comment", "ACGTAC"), ("r2", "first comment", "TTTTGG")]   # comment buffer is shared
+    q = tmp_path / "b.fq.gz"
+    with gzip.open(q, "wb") as fh:
+        fh.write(b"@q1 c1\nACGT\n+\nIIII\n@q2\tx|y\nGG\nTT\n+anything\nII\nII\n")
+    assert _read(q) == [("q1", "c1", "ACGT"), ("q2", "x|y", "GGTT")]
+    assert _read(tmp_path / "missing.fa") is None
+    e = tmp_path / "c.fa"
+    e.write_bytes(b">only\n")
+    assert _read(e) == [("only", None, "")]
+
+
+def test_reader_errors_like_reference(built, tmp_path):
+    (tmp_path / "three.fa").write_text(">a\nAC\n>b\nAC\n>c\nAC\n")
+    (tmp_path / "one.fa").write_text(">a\nAC\n")
+    rc, so, se = _run(["edit", "three.fa"], tmp_path)
+    assert (rc, so, se) == (255, "", "FATAL ERROR: input fasta file has more than 2 sequences\n")
+    rc, so, se = _run(["edit", "one.fa"], tmp_path)
+    assert (rc, so, se) == (255, "", "FATAL ERROR: read_kstring: fail to read sequence\n")
+    (tmp_path / "big.fa").write_text(">a\nACGTACGT\n>b\nACG\n")
+    rc, so, se = _run(["fit", "big.fa"], tmp_path)
+    assert (rc, so, se) == (255, "", "FATAL ERROR: first sequence must be shorter than the second\n\n")

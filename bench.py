@@ -124,7 +124,7 @@ def main():
     d_res = torch.zeros((4, pairs), dtype=torch.int32, device=dev)     # score, end_i, end_j, state
     d_nops = torch.zeros(pairs, dtype=torch.int32, device=dev)
     d_ops = torch.zeros(pairs * (l1 + l2) + 64, dtype=torch.uint8, device=dev) if tb else None
-    gathered = [torch.empty((world, 4, pairs), dtype=torch.int32, device=dev) for _ in range(2)] if world > 1 else None
+    gathered = [torch.empty((world * 4, pairs), dtype=torch.int32, device=dev) for _ in range(2)] if world > 1 else None
 
     def step(k):
         stream = torch.cuda.current_stream().cuda_stream

@@ -198,6 +198,12 @@ extern "C" int at_render(const uint8_t *ops, int32_t nops, const uint8_t *s1, in
 
 /* ----------------------------------------------------------------- dispatch */
 
+static long long env_ll(const char *name, long long dflt)
+{
+	const char *v = getenv(name);
+	return v && *v ? atoll(v) : dflt;
+}
+
 struct Layout {
 	int off_bound, off_ptr, k, ptr_lanes;
 	long long words;
@@ -233,25 +239,34 @@ static Layout layout_for(int kmode, int bits, bool tb, int max_l1, int max_l2)
 
 /* ---- packed int16 path (at_sweep16.hip.h): two same-shape pairs per wave ---- */
 struct Layout16 {
-	int off_refb, off_bound, off_ptr, k, ptr_lanes;
+	int off_refb, off_bound, off_ptr, g, k, ptr_lanes;
 	long long words;
 };
 
+/* Group width: reads of 97..208 bases run as 4 groups of 16 lanes x K rows (8 alignments per wave, 85 % of the
+ * lane-steps inside a 150 x 150 matrix instead of 59 %); everything else as one group of 64 lanes. */
 static Layout16 layout16_for(bool tb, int l1, int l2)
 {
-	const int tbk = (l2 + 63 + at::kBlk - 1) / at::kBlk;
 	Layout16 L;
+	const long long g_forced = env_ll("AT_GROUP", 0);
+	L.g = 64;
 	L.k = rows_per_lane(l1);
-	L.ptr_lanes = std::max(1, std::min(64, (l1 + L.k - 1) / L.k));
-	const long long nstrips = (l1 + 64 * L.k - 1) / (64 * L.k);
+	if (g_forced != 64 && l1 > 96 && l1 <= 208) {
+		L.g = 16;
+		L.k = l1 <= 112 ? 7 : (l1 <= 160 ? 10 : 13);
+	}
+	const int ng = 64 / L.g;
+	const int tbk = (l2 + L.g - 1 + at::kBlk - 1) / at::kBlk;
+	L.ptr_lanes = L.g == 64 ? std::max(1, std::min(64, (l1 + L.k - 1) / L.k)) : 64;
+	const long long nstrips = (l1 + L.g * L.k - 1) / (L.g * L.k);
 	long long nref = (at::kPad + (long long)tbk * at::kBlk) / 4 + 4;
 	nref = (nref + 1) & ~1LL;
 	const long long nbound = 2LL * (l2 + 2);
 	const long long nptr = tb ? nstrips * tbk * 2 * L.k * L.ptr_lanes + 64 : 0;
 	L.off_refb = (int)nref;
-	L.off_bound = (int)(2 * nref);
-	L.off_ptr = (int)(2 * nref + nbound);
-	L.words = 2 * nref + nbound + nptr;
+	L.off_bound = (int)(2 * nref * ng);
+	L.off_ptr = (int)(2 * nref * ng + nbound);
+	L.words = 2 * nref * ng + nbound + nptr;
 	return L;
 }
 
@@ -308,11 +323,6 @@ static int ensure_sitemask(at_handle *h, int max_l2, hipStream_t stream)
 	return AT_OK;
 }
 
-static long long env_ll(const char *name, long long dflt)
-{
-	const char *v = getenv(name);
-	return v && *v ? atoll(v) : dflt;
-}
 
 
 /* Storage class + grid for one launch.
@@ -419,10 +429,13 @@ extern "C" int at_align_batch_device(at_handle *h, int mode, int64_t npairs,
 		b.ops = d_ops; b.ops_off = (const long long *)d_ops_off; b.nops = d_nops;
 		b.off_refb = P.off_refb; b.off_bound = P.off_bound; b.ptr_lanes = P.ptr_lanes;
 		Plan pl;
-		int rc = plan_launch(h, "packed16", P.k, (npairs + 1) / 2, P.off_ptr, P.words - P.off_ptr, &pl, stream);
+		const int per_wave = 2 * (64 / P.g);
+		char tag16[48];
+		snprintf(tag16, sizeof tag16, "packed16 %dx%d-lane groups (%d pairs/wave)", 64 / P.g, P.g, per_wave);
+		int rc = plan_launch(h, tag16, P.k, (npairs + per_wave - 1) / per_wave, P.off_ptr, P.words - P.off_ptr, &pl, stream);
 		if (rc) return rc;
 		b.off_ptr = pl.off_ptr; b.ws = pl.ws; b.ws_slot_words = pl.slot_words; b.queue = h->d_queue;
-		at_sweep16_fn fn16 = at_pick16(kmode, P.k, pl.store, tb);
+		at_sweep16_fn fn16 = at_pick16(kmode, P.g, P.k, pl.store, tb);
 		if (pl.dyn_lds > 48 * 1024)
 			HIP_TRY(h, hipFuncSetAttribute((const void *)fn16, hipFuncAttributeMaxDynamicSharedMemorySize, (int)pl.dyn_lds));
 		hipLaunchKernelGGL(fn16, dim3((unsigned)pl.grid), dim3(64), pl.dyn_lds, stream, b);

@@ -1,10 +1,15 @@
 /*
  * at_sweep16.hip.h -- packed-int16 variant of the anti-diagonal sweep (gfx950).
  *
- * Same geometry as at_sweep.hip.h (one wavefront per sweep, K rows per lane,
- * DPP wave_shr:1 for the cell above, time-major pointers), but every 32-bit
- * register carries TWO alignments of the same shape (l1, l2): pair A in bits
- * [15:0], pair B in bits [31:16].  gfx950 issues v_pk_add_i16 / v_pk_max_i16 at
+ * Same geometry as at_sweep.hip.h (K rows per lane, DPP shift for the cell
+ * above, time-major pointers), but every 32-bit register carries TWO alignments
+ * of the same shape (l1, l2): pair A in bits [15:0], pair B in bits [31:16].
+ * With G = 64 one wavefront sweeps one such pair of alignments; with G = 16 the
+ * wavefront is four independent groups of 16 lanes (DPP row_shr:1 stays inside a
+ * row of 16), each sweeping its own two alignments with K = ceil(l1/16) rows per
+ * lane -- 8 alignments per wavefront.  For 150 x 150 that cuts the ramp from
+ * 49 + 150 steps on 50 lanes (59 % of lane-steps inside the matrix) to 14 + 150
+ * steps on 15 of 16 lanes (85 %).  gfx950 issues v_pk_add_i16 / v_pk_max_i16 at
  * the same rate as the 32-bit integer max (measured: tools/valu_rate*.hip), and
  * the tag/clean/pointer logic is bitwise, so one instruction stream fills two
  * DP matrices.  Used for batches of uniform shape whose scores provably fit:
@@ -112,13 +117,24 @@ AT_DEV uint32_t pick(const uint32_t (&v)[K], int r)
 	return x;
 }
 
-template <int MODE, int K, bool SMALL, bool PTRLDS, bool TB>
+/* shift up by one lane inside a group of G lanes; lane 0 of each group keeps `old` */
+template <int G>
+AT_DEV uint32_t grp_up1(uint32_t old, uint32_t src)
+{
+	if constexpr (G == 64) return (uint32_t)__builtin_amdgcn_update_dpp((int)old, (int)src, 0x138 /* wave_shr:1 */, 0xf, 0xf, false);
+	else return (uint32_t)__builtin_amdgcn_update_dpp((int)old, (int)src, 0x111 /* row_shr:1 */, 0xf, 0xf, false);
+}
+
+template <int MODE, int G, int K, bool SMALL, bool PTRLDS, bool TB>
 __global__ __launch_bounds__(64) void at_sweep16(const Sweep16Args a)
 {
 	static_assert(MODE == K_GLOBAL || MODE == K_LOCAL || MODE == K_FIT, "packed path: 3-state modes without the jump state");
-	constexpr int RS = 64 * K;
+	static_assert(G == 64 || G == 16, "group width");
+	constexpr int NG = 64 / G;                /* groups per wavefront, 2 alignments each */
+	constexpr int RS = G * K;                 /* rows per strip (G < 64: the only strip) */
 	constexpr int PADW = kPad / 4;            /* s2 bytes: 4 per word */
 	const int lane = threadIdx.x;
+	const int grp = lane / G, lg = lane % G;
 	Slot<SMALL> mem;
 	mem.g = SMALL ? nullptr : a.ws + (long long)blockIdx.x * a.ws_slot_words;
 	PtrStore<PTRLDS> pm;
@@ -130,40 +146,42 @@ __global__ __launch_bounds__(64) void at_sweep16(const Sweep16Args a)
 	uint32_t lut_lo = ((uint32_t)a.m16 & 0xffu) | (((uint32_t)a.u16 & 0xffu) * 0x01010100u);
 	uint32_t lut_hi = (((uint32_t)a.m16 >> 8) & 0xffu) | ((((uint32_t)a.u16 >> 8) & 0xffu) * 0x01010100u);
 	/* constants live in VGPRs: VOP3 encodings take no 32-bit literals, and a literal would split and_or into two ops */
-	uint32_t cClean = kClean2, cTagM = kTagM2, cTagL = kTagL2, cTagU = kTagU2, c04 = 0x04000400u;
+	uint32_t cClean = kClean2, cTagM = kTagM2, cTagL = kTagL2, cTagU = kTagU2;
 	uint32_t cM3 = 0x00030003u, cM7 = 0x00070007u, cF0 = 0xf0u;
 	asm volatile("" : "+v"(o2), "+v"(e2), "+v"(lut_lo), "+v"(lut_hi));
-	asm volatile("" : "+v"(cClean), "+v"(cTagM), "+v"(cTagL), "+v"(cTagU), "+v"(c04), "+v"(cM3), "+v"(cM7), "+v"(cF0));
-	const int nstrips = (l1 + RS - 1) / RS;
-	const int tbk = (l2 + 63 + kBlk - 1) / kBlk;
+	asm volatile("" : "+v"(cClean), "+v"(cTagM), "+v"(cTagL), "+v"(cTagU), "+v"(cM3), "+v"(cM7), "+v"(cF0));
+	const int nstrips = (l1 + RS - 1) / RS;   /* host guarantees 1 when G < 64 */
+	const int tbk = (l2 + G - 1 + kBlk - 1) / kBlk;
 	const int wps = tbk * 2 * K;              /* pointer word rows per strip: 4 steps per word */
-	const int lastlane = l1 > 0 ? ((l1 - 1) % RS) / K : 0;
+	const int lastlane = l1 > 0 ? ((l1 - 1) % RS) / K : 0;   /* lane-in-group owning row l1 */
 	const int rl = l1 > 0 ? ((l1 - 1) % RS) % K : 0;
-	const long long nwork = (a.npairs + 1) >> 1;
+	const long long nwork = (a.npairs + 2 * NG - 1) / (2 * NG);
+	const int refoff = grp * 2 * a.off_refb;  /* my group's two s2 byte arrays */
 
 	long long wnext = next_work(a.queue, lane);
 	while (wnext < nwork) {
 		const long long wk = wnext;
 		wnext = next_work(a.queue, lane);   /* consumed at the end of this work item: latency hidden */
-		const long long pA = 2 * wk;
-		const long long pB = (2 * wk + 1 < a.npairs) ? 2 * wk + 1 : pA;
+		const long long last = a.npairs - 1;
+		const long long pA = (wk * NG + grp) * 2 < a.npairs ? (wk * NG + grp) * 2 : last;
+		const long long pB = (wk * NG + grp) * 2 + 1 < a.npairs ? (wk * NG + grp) * 2 + 1 : last;
 		const uint32_t *qA = a.seq + a.woff1[pA], *qB = a.seq + a.woff1[pB];
 		const uint32_t *rA = a.seq + a.woff2[pA], *rB = a.seq + a.woff2[pB];
 
-		/* ---- stage both s2 as bytes (coalesced int32 reads of the 2-bit words) ---- */
+		/* ---- stage both s2 of my group as bytes (coalesced int32 reads of the 2-bit words) ---- */
 		{
 			const int nw2 = (l2 + 15) >> 4;
-			for (int w = lane; w < nw2; w += 64) {
+			for (int w = lg; w < nw2; w += G) {
 				const uint32_t va = rA[w], vb = rB[w];
 #pragma unroll
 				for (int q = 0; q < 4; ++q) {
 					const uint32_t ba = (va >> (8 * q)) & 0xffu, bb = (vb >> (8 * q)) & 0xffu;
-					mem.st(PADW + 4 * w + q, (ba & 3u) | ((ba & 0xcu) << 6) | ((ba & 0x30u) << 12) | ((ba & 0xc0u) << 18));
-					mem.st(a.off_refb + PADW + 4 * w + q, (bb & 3u) | ((bb & 0xcu) << 6) | ((bb & 0x30u) << 12) | ((bb & 0xc0u) << 18));
+					mem.st(refoff + PADW + 4 * w + q, (ba & 3u) | ((ba & 0xcu) << 6) | ((ba & 0x30u) << 12) | ((ba & 0xc0u) << 18));
+					mem.st(refoff + a.off_refb + PADW + 4 * w + q, (bb & 3u) | ((bb & 0xcu) << 6) | ((bb & 0x30u) << 12) | ((bb & 0xc0u) << 18));
 				}
 			}
 		}
-		/* ---- boundary row 0 (identical for both pairs) ---- */
+		/* ---- boundary row 0 (identical for every alignment of the batch) ---- */
 		for (int j = lane; j <= l2; j += 64) {
 			int L, M, U;
 			border16<MODE>(0, j, o16, e16, L, M, U);
@@ -180,20 +198,22 @@ __global__ __launch_bounds__(64) void at_sweep16(const Sweep16Args a)
 
 		for (int s = 0; s < nstrips; ++s) {
 			const int base = s * RS;
-			const int i0 = base + lane * K;
-			const int nl = imin(64, (l1 - base + K - 1) / K);
+			const int i0 = base + lg * K;
+			const int nl = imin(G, (l1 - base + K - 1) / K);
 			const bool laststrip = s == nstrips - 1;
-			const bool wb = !laststrip;
-			uint32_t qrA[K], qrB[K], acc[K], keymask[K], rowtag[K];
+			const bool wb = G == 64 && !laststrip;
+			uint32_t qsel[K], acc[K], keymask[K];
 #pragma unroll
 			for (int r = 0; r < K; ++r) {
 				const int qi = imin(i0 + r, l1 - 1);
-				qrA[r] = ((qA[qi >> 4] >> ((qi & 15) * 2)) & 3u) * 0x01010101u;
-				qrB[r] = ((qB[qi >> 4] >> ((qi & 15) * 2)) & 3u) * 0x01010101u;
+				const uint32_t ca = (qA[qi >> 4] >> ((qi & 15) * 2)) & 3u, cb = (qB[qi >> 4] >> ((qi & 15) * 2)) & 3u;
+				/* my query bases of both alignments as the bytes {qB|4, qB, qA|4, qA}: xor-ing the s2 bytes {b,b,a,a}
+				 * onto it gives the LUT selector directly (codes are < 4, so the |4 survives the xor) */
+				qsel[r] = (ca * 0x00000101u + cb * 0x01010000u) | 0x04000400u;
 				acc[r] = 0;
-				const bool valid = i0 + r < l1;
-				keymask[r] = valid ? kClean2 : 0u;
-				rowtag[r] = valid ? (uint32_t)(K - 1 - r) * 0x00010001u : 0x80008000u;
+				/* rows past l1 (only in the last lane that owns rows): their key collapses to the bare row tag,
+				 * which every real row of the lane beats (smaller r = larger tag, score >= 0) */
+				keymask[r] = i0 + r < l1 ? kClean2 : 0u;
 				int L, M, U;
 				border16<MODE>(i0 + r + 1, 0, o16, e16, L, M, U);
 				L = sat16(L);
@@ -222,60 +242,59 @@ __global__ __launch_bounds__(64) void at_sweep16(const Sweep16Args a)
 			for (int blk = 0; blk < tbk; ++blk) {
 				const int t0 = blk * kBlk;
 				load_bound(t0 + kBlk, bxn, bln);
-				/* ---- s2 windows: bytes t0-lane .. t0-lane+7 of both pairs, xor my K query bases ---- */
-				uint32_t xA[2][K], xB[2][K];
+				/* ---- s2 windows: bytes t0-lg .. t0-lg+7 of both alignments ---- */
+				uint32_t wA[2], wB[2];
 				{
-					const int e0 = t0 - lane + kPad;
-					const int w = e0 >> 2;
+					const int e0 = t0 - lg + kPad;
+					const int w = refoff + (e0 >> 2);
 					const int sh = (e0 & 3) * 8;
 					const uint32_t a0 = mem.ld(w), a1 = mem.ld(w + 1), a2 = mem.ld(w + 2);
 					const uint32_t b0 = mem.ld(a.off_refb + w), b1 = mem.ld(a.off_refb + w + 1), b2 = mem.ld(a.off_refb + w + 2);
-					const uint32_t alo = __builtin_amdgcn_alignbit(a1, a0, sh), ahi = __builtin_amdgcn_alignbit(a2, a1, sh);
-					const uint32_t blo = __builtin_amdgcn_alignbit(b1, b0, sh), bhi = __builtin_amdgcn_alignbit(b2, b1, sh);
-#pragma unroll
-					for (int r = 0; r < K; ++r) {
-						xA[0][r] = alo ^ qrA[r]; xA[1][r] = ahi ^ qrA[r];
-						xB[0][r] = blo ^ qrB[r]; xB[1][r] = bhi ^ qrB[r];
-					}
+					wA[0] = __builtin_amdgcn_alignbit(a1, a0, sh); wA[1] = __builtin_amdgcn_alignbit(a2, a1, sh);
+					wB[0] = __builtin_amdgcn_alignbit(b1, b0, sh); wB[1] = __builtin_amdgcn_alignbit(b2, b1, sh);
 				}
-				const int jm1_0 = t0 - lane;
+				const int jm1_0 = t0 - lg;
 
 				auto step = [&](auto KC, auto MASKED) {
 					constexpr int k = decltype(KC)::value;
 					constexpr bool masked = decltype(MASKED)::value;
 					constexpr int kk = k & 3, hw = k >> 2;
-					/* selector picking byte kk of xA (pool 0..3) twice and of xB (pool 4..7) twice */
+					/* selector picking byte kk of the A window (pool 0..3) twice and of the B window (pool 4..7) twice */
 					constexpr uint32_t SELK = (uint32_t)kk * 0x00000101u + (uint32_t)(4 + kk) * 0x01010000u;
 					const int t = t0 + k;
 					uint32_t tpk = pk2(t);
 					asm("" : "+v"(tpk));
-					const uint32_t Aup = (uint32_t)shfl_up1((int)row_shl<k>((int)bx), (int)A_prev);
-					const uint32_t Bup = (uint32_t)shfl_up1((int)row_shl<k>((int)bl), (int)B_prev);
+					const uint32_t Aup = grp_up1<G>((uint32_t)row_shl<k>((int)bx), A_prev);
+					const uint32_t Bup = grp_up1<G>((uint32_t)row_shl<k>((int)bl), B_prev);
 					const int jm1 = jm1_0 + k;
 					bool active = true;
-					if constexpr (masked) active = lane < nl && (unsigned)jm1 < (unsigned)l2;
+					if constexpr (masked) active = lg < nl && (unsigned)jm1 < (unsigned)l2;
 					uint32_t pbyte[K];
 #pragma unroll
 					for (int r = 0; r < K; ++r) pbyte[r] = 0;
 					if (active) {
 						if constexpr (MODE == K_FIT) {
 							/* end-cell scan of row l1, columns 0..l2-1 (:676-690), one column behind the sweep;
-							 * every lane scans its own row rl, only lane `lastlane` is read at the end */
+							 * every lane scans its own row rl, only the owner of row l1 is read at the end */
 							if (laststrip) {
 								const uint32_t jpk = pk2(jm1);
 								const uint32_t vM = psub(pick<K>(Mo_l, rl), o2);
-								uint32_t g = pneg(psub(bestM, vM));
-								bestMj = bfi(g, jpk, bestMj); bestM = pmax(bestM, vM);
+								uint32_t dM = psub(bestM, vM);
+								asm("" : "+v"(dM));
+								bestMj = vbfi(pneg(dM), jpk, bestMj); bestM = pmax(bestM, vM);
 								const uint32_t vL = pick<K>(L_l, rl);
-								g = pneg(psub(bestL, vL));
-								bestLj = bfi(g, jpk, bestLj); bestL = pmax(bestL, vL);
+								uint32_t dL = psub(bestL, vL);
+								asm("" : "+v"(dL));
+								bestLj = vbfi(pneg(dL), jpk, bestLj); bestL = pmax(bestL, vL);
 							}
 						}
+						/* step k's byte of each window against each of my query bases */
+						const uint32_t selw = __builtin_amdgcn_perm(wB[hw], wA[hw], SELK);   /* [b, b, a, a] */
 						uint32_t diag = Ad, lraw = Bup, up = 0, cmax = 0;
 #pragma unroll
 						for (int r = 0; r < K; ++r) {
-							const uint32_t sel = __builtin_amdgcn_perm(xB[hw][r], xA[hw][r], SELK) | c04;
-							const uint32_t S = __builtin_amdgcn_perm(lut_hi, lut_lo, sel);
+							/* x = s2 byte ^ query byte (0 = match): selector {xB+4, xB, xA+4, xA} -> the two 16-bit scores */
+							const uint32_t S = __builtin_amdgcn_perm(lut_hi, lut_lo, selw ^ qsel[r]);
 							uint32_t Mraw = padd(diag, S);
 							if constexpr (MODE == K_LOCAL) Mraw = pmax(Mraw, 0u);
 							const uint32_t Mc = vandor(Mraw, cClean, cTagM);
@@ -292,7 +311,8 @@ __global__ __launch_bounds__(64) void at_sweep16(const Sweep16Args a)
 								pbyte[r] = vbfi(cF0, __builtin_amdgcn_alignbit(nib, nib, 12), nib);
 							}
 							if constexpr (MODE == K_LOCAL) {
-								const uint32_t key = vandor(Mraw, keymask[r], rowtag[r]);
+								uint32_t rt = (uint32_t)(K - 1 - r) * 0x00010001u;
+								const uint32_t key = (Mraw & keymask[r]) | rt;
 								cmax = r == 0 ? key : pmax(cmax, key);
 							}
 							diag = Xl[r];
@@ -340,10 +360,11 @@ __global__ __launch_bounds__(64) void at_sweep16(const Sweep16Args a)
 				for (int h = 0; h < 2; ++h) {
 					const int key = half(best, h);
 					const int sc = key & ~15;
-					if (key != kNeg16 && sc > gbs[h]) {
+					const int row = i0 + (K - 1 - (key & 15)) + 1;
+					if (key != kNeg16 && row <= l1 && sc > gbs[h]) {
 						gbs[h] = sc;
-						gbi[h] = i0 + (K - 1 - (key & 15)) + 1;
-						gbj[h] = (int)((bt >> (16 * h)) & 0xffffu) - lane + 1;
+						gbi[h] = row;
+						gbj[h] = (int)((bt >> (16 * h)) & 0xffffu) - lg + 1;
 					}
 				}
 			}
@@ -351,32 +372,37 @@ __global__ __launch_bounds__(64) void at_sweep16(const Sweep16Args a)
 		}
 
 		pm.ready();
-		/* ================= per pair: end cell, traceback, outputs ================= */
+		/* ================= per alignment: end cell, traceback, outputs ================= */
 #pragma unroll 1
-		for (int h = 0; h < 2; ++h) {
-			const long long p = h ? pB : pA;
-			if (h == 1 && pB == pA) break;
+		for (int gh = 0; gh < 2 * NG; ++gh) {
+			const int g = gh >> 1, h = gh & 1;
+			const long long p = (wk * NG + g) * 2 + h;
+			if (p >= a.npairs) break;
+			const int glane = g * G;               /* lane 0 of the group */
 			int sc16 = 0, ci = 0, cj = 0, st = 2;
 			bool ok = true;
 			if constexpr (MODE == K_LOCAL) {
 				int bs = gbs[h], bi = gbi[h], bj = gbj[h];
-				for (int d = 32; d >= 1; d >>= 1) {
+				for (int d = G / 2; d >= 1; d >>= 1) {
 					const int ob = __shfl_xor(bs, d), oi = __shfl_xor(bi, d), oj = __shfl_xor(bj, d);
 					const bool take = ob > bs || (ob == bs && (oi < bi || (oi == bi && oj < bj)));
 					if (take) { bs = ob; bi = oi; bj = oj; }
 				}
-				sc16 = uni(bs); ci = uni(bi); cj = uni(bj); st = 2;
+				sc16 = __builtin_amdgcn_readlane(bs, glane); ci = __builtin_amdgcn_readlane(bi, glane);
+				cj = __builtin_amdgcn_readlane(bj, glane); st = 2;
 			} else if constexpr (MODE == K_GLOBAL) {
-				const int eL = half((uint32_t)__builtin_amdgcn_readlane((int)pick<K>(L_l, rl), lastlane), h);
-				const int eM = half(psub((uint32_t)__builtin_amdgcn_readlane((int)pick<K>(Mo_l, rl), lastlane), pk2(o16)), h);
-				const int eU = half((uint32_t)__builtin_amdgcn_readlane((int)pick<K>(U_l, rl), lastlane), h);
+				const int own = glane + lastlane;
+				const int eL = half((uint32_t)__builtin_amdgcn_readlane((int)pick<K>(L_l, rl), own), h);
+				const int eM = half(psub((uint32_t)__builtin_amdgcn_readlane((int)pick<K>(Mo_l, rl), own), pk2(o16)), h);
+				const int eU = half((uint32_t)__builtin_amdgcn_readlane((int)pick<K>(U_l, rl), own), h);
 				const int x = imax3(eL, eM, eU);
 				sc16 = x; st = x & 3; ci = l1; cj = l2;
 			} else {
-				const int bM = half((uint32_t)__builtin_amdgcn_readlane((int)bestM, lastlane), h);
-				const int jM = half((uint32_t)__builtin_amdgcn_readlane((int)bestMj, lastlane), h);
-				const int bL = half((uint32_t)__builtin_amdgcn_readlane((int)bestL, lastlane), h);
-				const int jL = half((uint32_t)__builtin_amdgcn_readlane((int)bestLj, lastlane), h);
+				const int own = glane + lastlane;
+				const int bM = half((uint32_t)__builtin_amdgcn_readlane((int)bestM, own), h);
+				const int jM = half((uint32_t)__builtin_amdgcn_readlane((int)bestMj, own), h);
+				const int bL = half((uint32_t)__builtin_amdgcn_readlane((int)bestL, own), h);
+				const int jL = half((uint32_t)__builtin_amdgcn_readlane((int)bestLj, own), h);
 				ci = l1;
 				if ((bL >> kShift) > (bM >> kShift) && bL > a.thresh16) { sc16 = bL; st = 3; cj = jL; }
 				else { sc16 = bM; st = 2; cj = jM; }
@@ -396,7 +422,7 @@ __global__ __launch_bounds__(64) void at_sweep16(const Sweep16Args a)
 					const int ss = (ii - 1) / RS, li = (ii - 1) % RS;
 					const int ln = li / K, r = li % K;
 					const int t = (jj - 1) + ln;
-					const uint32_t w = pm.ld(a.off_ptr + (ss * wps + (t >> 2) * K + r) * NL + ln);
+					const uint32_t w = pm.ld(a.off_ptr + (ss * wps + (t >> 2) * K + r) * NL + glane + ln);
 					return (uint32_t)uni((int)((w >> ((t & 3) * 8 + 4 * h)) & 15u));
 				};
 				int guard = l1 + l2 + 2;

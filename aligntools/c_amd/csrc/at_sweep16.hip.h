@@ -67,6 +67,11 @@ AT_DEV uint32_t pmax(uint32_t a, uint32_t b)
 {
 	return __builtin_bit_cast(uint32_t, __builtin_elementwise_max(__builtin_bit_cast(s16x2, a), __builtin_bit_cast(s16x2, b)));
 }
+/* shift each 16-bit half left by 4 (v_pk_lshlrev_b16) */
+AT_DEV uint32_t pshl4(uint32_t a)
+{
+	return __builtin_bit_cast(uint32_t, __builtin_bit_cast(s16x2, a) << (s16x2)(4));
+}
 /* 0xffff in every half that is negative */
 AT_DEV uint32_t pneg(uint32_t a)
 {
@@ -117,6 +122,11 @@ AT_DEV uint32_t pick(const uint32_t (&v)[K], int r)
 	return x;
 }
 
+/* second __launch_bounds__ argument = waves per SIMD the register allocator must leave room for */
+#ifndef AT_WAVES16
+#define AT_WAVES16(G, K) ((G) == 16 && (K) >= 10 ? 3 : 1)
+#endif
+
 /* shift up by one lane inside a group of G lanes; lane 0 of each group keeps `old` */
 template <int G>
 AT_DEV uint32_t grp_up1(uint32_t old, uint32_t src)
@@ -126,7 +136,7 @@ AT_DEV uint32_t grp_up1(uint32_t old, uint32_t src)
 }
 
 template <int MODE, int G, int K, bool SMALL, bool PTRLDS, bool TB>
-__global__ __launch_bounds__(64) void at_sweep16(const Sweep16Args a)
+__global__ __launch_bounds__(64, AT_WAVES16(G, K)) void at_sweep16(const Sweep16Args a)
 {
 	static_assert(MODE == K_GLOBAL || MODE == K_LOCAL || MODE == K_FIT, "packed path: 3-state modes without the jump state");
 	static_assert(G == 64 || G == 16, "group width");
@@ -147,9 +157,9 @@ __global__ __launch_bounds__(64) void at_sweep16(const Sweep16Args a)
 	uint32_t lut_hi = (((uint32_t)a.m16 >> 8) & 0xffu) | ((((uint32_t)a.u16 >> 8) & 0xffu) * 0x01010100u);
 	/* constants live in VGPRs: VOP3 encodings take no 32-bit literals, and a literal would split and_or into two ops */
 	uint32_t cClean = kClean2, cTagM = kTagM2, cTagL = kTagL2, cTagU = kTagU2;
-	uint32_t cM3 = 0x00030003u, cM7 = 0x00070007u, cF0 = 0xf0u;
+	uint32_t cM3 = 0x00030003u, cM7 = 0x00070007u, cNib = 0x000f000fu;
 	asm volatile("" : "+v"(o2), "+v"(e2), "+v"(lut_lo), "+v"(lut_hi));
-	asm volatile("" : "+v"(cClean), "+v"(cTagM), "+v"(cTagL), "+v"(cTagU), "+v"(cM3), "+v"(cM7), "+v"(cF0));
+	asm volatile("" : "+v"(cClean), "+v"(cTagM), "+v"(cTagL), "+v"(cTagU), "+v"(cM3), "+v"(cM7), "+v"(cNib));
 	const int nstrips = (l1 + RS - 1) / RS;   /* host guarantees 1 when G < 64 */
 	const int tbk = (l2 + G - 1 + kBlk - 1) / kBlk;
 	const int wps = tbk * 2 * K;              /* pointer word rows per strip: 4 steps per word */
@@ -269,9 +279,6 @@ __global__ __launch_bounds__(64) void at_sweep16(const Sweep16Args a)
 					const int jm1 = jm1_0 + k;
 					bool active = true;
 					if constexpr (masked) active = lg < nl && (unsigned)jm1 < (unsigned)l2;
-					uint32_t pbyte[K];
-#pragma unroll
-					for (int r = 0; r < K; ++r) pbyte[r] = 0;
 					if (active) {
 						if constexpr (MODE == K_FIT) {
 							/* end-cell scan of row l1, columns 0..l2-1 (:676-690), one column behind the sweep;
@@ -307,8 +314,8 @@ __global__ __launch_bounds__(64) void at_sweep16(const Sweep16Args a)
 							if constexpr (TB) {
 								uint32_t nib = vbfi(cM3, Mraw, lraw);
 								nib = vbfi(cM7, nib, Uraw);
-								/* byte = [nibble of B | nibble of A] */
-								pbyte[r] = vbfi(cF0, __builtin_amdgcn_alignbit(nib, nib, 12), nib);
+								/* each half keeps its own 4-step shift register: acc = acc << 4 | nibble */
+								acc[r] = vandor(nib, cNib, pshl4(acc[r]));
 							}
 							if constexpr (MODE == K_LOCAL) {
 								uint32_t rt = (uint32_t)(K - 1 - r) * 0x00010001u;
@@ -332,10 +339,13 @@ __global__ __launch_bounds__(64) void at_sweep16(const Sweep16Args a)
 						A_prev = up; B_prev = lraw;
 						if (wb && lane == 63) mem.st2(a.off_bound + 2 * (jm1 + 1), up, lraw);
 					}
+					else if constexpr (TB && masked) {
+						/* keep the shift registers in step: nibble k of a word is always step k of its 4-step group */
+#pragma unroll
+						for (int r = 0; r < K; ++r) acc[r] = pshl4(acc[r]);
+					}
 					Ad = Aup;
 					if constexpr (TB) {
-#pragma unroll
-						for (int r = 0; r < K; ++r) acc[r] = __builtin_amdgcn_alignbit(pbyte[r], acc[r], 8);
 						if ((k & 3) == 3 && lane < NL) {
 #pragma unroll
 							for (int r = 0; r < K; ++r) pm.st(ptr_base + ((blk * 2 + hw) * K + r) * NL + lane, acc[r]);
@@ -423,7 +433,7 @@ __global__ __launch_bounds__(64) void at_sweep16(const Sweep16Args a)
 					const int ln = li / K, r = li % K;
 					const int t = (jj - 1) + ln;
 					const uint32_t w = pm.ld(a.off_ptr + (ss * wps + (t >> 2) * K + r) * NL + glane + ln);
-					return (uint32_t)uni((int)((w >> ((t & 3) * 8 + 4 * h)) & 15u));
+					return (uint32_t)uni((int)((w >> (16 * h + 4 * (3 - (t & 3)))) & 15u));
 				};
 				int guard = l1 + l2 + 2;
 				if (ok) {

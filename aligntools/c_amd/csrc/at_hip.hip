@@ -226,7 +226,8 @@ static Layout layout_for(int kmode, int bits, bool tb, int max_l1, int max_l2)
 	L.k = rows_per_lane(max_l1);
 	L.ptr_lanes = std::max(1, std::min(64, (max_l1 + L.k - 1) / L.k));
 	const long long nstrips = (max_l1 + 64 * L.k - 1) / (64 * L.k);
-	long long nref = (at::kPad + (long long)tbk * at::kBlk + 16) / bpw + 3;
+	(void)bpw;
+	long long nref = (at::kPad + (long long)tbk * at::kBlk) / 4 + 4;   /* s2 staged one byte per base */
 	nref = (nref + 1) & ~1LL;
 	const long long nbound = 2LL * (max_l2 + 2);
 	const long long nptr = (tb && kmode != at::K_EDIT) ? nstrips * tbk * rpb * L.k * L.ptr_lanes + 64 : 0;
@@ -236,6 +237,16 @@ static Layout layout_for(int kmode, int bits, bool tb, int max_l1, int max_l2)
 	return L;
 }
 
+
+/* The 2-bit kernels read scores from a signed-byte LUT: scaled match/mismatch (minus the gap for overlap) must fit. */
+static bool scores_fit_byte(const at_handle *h, int mode)
+{
+	long long a, b;
+	if (mode == AT_MODE_EDIT) { a = 0; b = h->u; }
+	else if (mode == AT_MODE_OVERLAP) { a = 16LL * (h->m - h->o); b = 16LL * (h->u - h->o); }
+	else { a = 16LL * h->m; b = 16LL * h->u; }
+	return std::llabs(a) <= 127 && std::llabs(b) <= 127;
+}
 
 /* ---- packed int16 path (at_sweep16.hip.h): two same-shape pairs per wave ---- */
 struct Layout16 {
@@ -411,6 +422,8 @@ extern "C" int at_align_batch_device(at_handle *h, int mode, int64_t npairs,
 		return fail(h, AT_ERR_RANGE, "scores may exceed the exact range: max|param|=%lld, l1+l2=%lld", maxabs,
 		            (long long)max_len1 + max_len2);
 
+	if (bits == 2 && !scores_fit_byte(h, mode))
+		return fail(h, AT_ERR_RANGE, "2-bit kernels need |16*score| <= 127 (m=%d u=%d o=%d): pack the batch with bits=8", h->m, h->u, h->o);
 	const int kmode = mode == AT_MODE_GLOBAL ? at::K_GLOBAL : mode == AT_MODE_LOCAL ? at::K_LOCAL
 	                : mode == AT_MODE_FIT ? (h->use_jump ? at::K_FITJ : at::K_FIT)
 	                : mode == AT_MODE_OVERLAP ? at::K_OVERLAP : at::K_EDIT;
@@ -509,6 +522,7 @@ extern "C" int at_align_batch(at_handle *h, int mode, int64_t npairs, const uint
 	int bits = 0;
 	int rc = at_pack_batch(npairs, seq_blob, off1, len1, off2, len2, 0, &bits, nullptr, (int64_t *)off1 /*unused*/, (int64_t *)off2);
 	if (rc) return rc;
+	if (bits == 2 && !scores_fit_byte(h, mode)) bits = 8;   /* large scores: byte-compare kernels */
 	const int64_t nwords = at_pack_words(npairs, len1, len2, bits);
 	std::vector<uint32_t> words((size_t)nwords);
 	std::vector<int64_t> woff1((size_t)npairs), woff2((size_t)npairs);

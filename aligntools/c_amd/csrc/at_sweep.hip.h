@@ -102,6 +102,19 @@ AT_DEV int imin3(int a, int b, int c) { return imin(imin(a, b), c); }
 AT_DEV int uni(int v) { return __builtin_amdgcn_readfirstlane(v); }
 /* (a & mask) | (b & ~mask) */
 AT_DEV uint32_t bfi(uint32_t mask, uint32_t a, uint32_t b) { return (a & mask) | (b & ~mask); }
+/* v_bfi_b32 / v_and_or_b32 spelled out: hipcc otherwise re-associates nested selects into longer and/or3 chains */
+AT_DEV uint32_t vbfi(uint32_t mask, uint32_t a, uint32_t b)
+{
+	uint32_t d;
+	asm("v_bfi_b32 %0, %1, %2, %3" : "=v"(d) : "v"(mask), "v"(a), "v"(b));
+	return d;
+}
+AT_DEV uint32_t vandor(uint32_t a, uint32_t m, uint32_t o)
+{
+	uint32_t d;
+	asm("v_and_or_b32 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(m), "v"(o));
+	return d;
+}
 
 template <bool SMALL>
 struct Slot {
@@ -216,7 +229,7 @@ __global__ __launch_bounds__(64) void at_sweep(const SweepArgs a)
 	constexpr int SPD = 32 / PB;              /* steps per pointer dword      */
 	constexpr int RPB = kBlk / SPD;           /* pointer word rows per block  */
 	constexpr int BPW = 32 / BITS;            /* bases per packed word        */
-	constexpr int PADW = kPad / BPW;
+	constexpr int PADW = kPad / 4;            /* s2 is staged one byte per base */
 	constexpr int RS = 64 * K;                /* rows per strip               */
 	constexpr uint32_t BMASK = (1u << BITS) - 1u;
 
@@ -231,6 +244,12 @@ __global__ __launch_bounds__(64) void at_sweep(const SweepArgs a)
 	int u16v = MODE == K_EDIT ? a.u_raw : (MODE == K_OVERLAP ? u16 - o16 : u16);
 	asm volatile("" : "+v"(u16v));
 	const int m16s = MODE == K_EDIT ? 0 : (MODE == K_OVERLAP ? m16 - o16 : m16);
+	/* signed-byte score LUT {match, mismatch x3} for the 2-bit path (the host guarantees both fit a byte) */
+	uint32_t lut8 = ((uint32_t)m16s & 0xffu) | (((uint32_t)u16v & 0xffu) * 0x01010100u);
+	/* penalties and bit masks in VGPRs: an SGPR operand makes v_add_u32 half-rate on gfx950 (tools/valu_rate.hip) */
+	int e16v = e16, o16v = o16, g16v = g16;
+	uint32_t cM3 = 3u, cM7 = 7u;
+	asm volatile("" : "+v"(lut8), "+v"(e16v), "+v"(o16v), "+v"(g16v), "+v"(cM3), "+v"(cM7));
 
 	long long pnext = next_work(a.queue, lane);
 	while (pnext < a.npairs) {
@@ -244,10 +263,22 @@ __global__ __launch_bounds__(64) void at_sweep(const SweepArgs a)
 		const int tbk = (l2 + 63 + kBlk - 1) / kBlk;   /* blocks per strip           */
 		const int wps = tbk * RPB * K;                 /* pointer word rows per strip */
 
-		/* ---- stage s2 (coalesced int32 reads) in front of kPad slack bases ---- */
+		/* ---- stage s2 (coalesced int32 reads) as one byte per base in front of kPad slack bytes;
+		 *      2-bit input is expanded to byte codes 0..3 so that v_perm_b32 can look scores up ---- */
 		{
 			const int nw2 = (l2 + BPW - 1) / BPW;
-			for (int w = lane; w < nw2; w += 64) mem.st(PADW + w, r_words[w]);
+			for (int w = lane; w < nw2; w += 64) {
+				const uint32_t v = r_words[w];
+				if constexpr (BITS == 8) {
+					mem.st(PADW + w, v);
+				} else {
+#pragma unroll
+					for (int q = 0; q < 4; ++q) {
+						const uint32_t b = (v >> (8 * q)) & 0xffu;
+						mem.st(PADW + 4 * w + q, (b & 3u) | ((b & 0xcu) << 6) | ((b & 0x30u) << 12) | ((b & 0xc0u) << 18));
+					}
+				}
+			}
 		}
 		/* ---- boundary row 0 ---- */
 		for (int j = lane; j <= l2; j += 64) {
@@ -287,7 +318,7 @@ __global__ __launch_bounds__(64) void at_sweep(const SweepArgs a)
 			for (int r = 0; r < K; ++r) {
 				const int qi = imin(i0 + r, l1 - 1);
 				const uint32_t qw = q_words[qi / BPW];
-				qrep[r] = ((qw >> ((qi % BPW) * BITS)) & BMASK) * (BITS == 2 ? 0x55555555u : 0x01010101u);
+				qrep[r] = ((qw >> ((qi % BPW) * BITS)) & BMASK) * 0x01010101u;
 				best_r[r] = INT32_MIN; bt_r[r] = 0; acc[r] = 0;
 				const int i = i0 + r + 1;
 				if constexpr (AFFINE) {
@@ -335,17 +366,24 @@ __global__ __launch_bounds__(64) void at_sweep(const SweepArgs a)
 				const int t0 = blk * kBlk;
 				load_bound(t0 + kBlk, bxn, bln);
 				/* ---- reference window: bases t0-lane .. t0-lane+7 against my K query bases ---- */
-				uint32_t xlo[K], xhi[K];
+				/* 2-bit input: xs[h][r] = four signed score bytes (steps 4h..4h+3 of row r) read from the byte LUT
+				 * {m,u,u,u} with the xor of s2 and query codes as selector.  8-bit input: the raw xor (0 = match). */
+				uint32_t xs[2][K];
 				{
 					const int e0 = t0 - lane + kPad;
-					const int w = e0 / BPW;
-					const int sh = (e0 % BPW) * BITS;
-					const uint32_t w0 = mem.ld(w), w1 = mem.ld(w + 1);
-					const uint32_t lo = __builtin_amdgcn_alignbit(w1, w0, sh);
-					uint32_t hi = 0;
-					if constexpr (BITS == 8) hi = __builtin_amdgcn_alignbit(mem.ld(w + 2), w1, sh);
+					const int w = e0 >> 2;
+					const int sh = (e0 & 3) * 8;
+					const uint32_t w0 = mem.ld(w), w1 = mem.ld(w + 1), w2 = mem.ld(w + 2);
+					const uint32_t lo = __builtin_amdgcn_alignbit(w1, w0, sh), hi = __builtin_amdgcn_alignbit(w2, w1, sh);
 #pragma unroll
-					for (int r = 0; r < K; ++r) { xlo[r] = lo ^ qrep[r]; xhi[r] = hi ^ qrep[r]; }
+					for (int r = 0; r < K; ++r) {
+						if constexpr (BITS == 2) {
+							xs[0][r] = __builtin_amdgcn_perm(0u, lut8, lo ^ qrep[r]);
+							xs[1][r] = __builtin_amdgcn_perm(0u, lut8, hi ^ qrep[r]);
+						} else {
+							xs[0][r] = lo ^ qrep[r]; xs[1][r] = hi ^ qrep[r];
+						}
+					}
 				}
 				uint32_t sm = 0;
 				if constexpr (HASJ) {
@@ -385,16 +423,19 @@ __global__ __launch_bounds__(64) void at_sweep(const SweepArgs a)
 						int diag = Ad, up = Aup, lraw = Bup;
 #pragma unroll
 						for (int r = 0; r < K; ++r) {
-							uint32_t mis;
-							if constexpr (BITS == 2) mis = (xlo[r] >> (2 * k)) & 3u;
-							else mis = ((k < 4 ? xlo[r] : xhi[r]) >> (8 * (k & 3))) & 0xffu;
-							const int s16 = mis ? u16v : m16s;
+							int s16;
+							if constexpr (BITS == 2) {
+								s16 = (int)(signed char)(xs[k >> 2][r] >> (8 * (k & 3)));   /* folds into an SDWA add */
+							} else {
+								const uint32_t mis = (xs[k >> 2][r] >> (8 * (k & 3))) & 0xffu;
+								s16 = mis ? u16v : m16s;
+							}
 							if constexpr (AFFINE) {
 								int Mraw = diag + s16;
 								if constexpr (MODE == K_LOCAL) Mraw = imax(Mraw, 0);
 								const int Mc = (Mraw & ~15) | kTagM;
 								const int Lc = lraw | kTagL;
-								const int Uraw = imax(Mo_l[r], U_l[r] + e16);
+								const int Uraw = imax(Mo_l[r], U_l[r] + e16v);
 								const int Uc = (Uraw & ~15) | kTagU;
 								int Jraw = 0, Jc = kNeg;
 								if constexpr (HASJ) {
@@ -402,13 +443,13 @@ __global__ __launch_bounds__(64) void at_sweep(const SweepArgs a)
 									Jraw = open_ok ? imax(Mg_l[r], J_l[r]) : J_l[r];
 									Jc = Jraw & ~15;
 								}
-								const int Mo = Mc + o16;
+								const int Mo = Mc + o16v;
 								int Xo = imax3(Lc, Mc, Uc);
 								if constexpr (HASJ) Xo = imax(Xo, Jc);
-								const int Ld = imax(Lc + e16, Mo);
+								const int Ld = imax(Lc + e16v, Mo);
 								if constexpr (TB) {
-									nib[r] = bfi(3u, (uint32_t)Mraw, (uint32_t)lraw);
-									nib[r] = bfi(7u, nib[r], (uint32_t)Uraw);
+									nib[r] = vbfi(cM3, (uint32_t)Mraw, (uint32_t)lraw);
+									nib[r] = vbfi(cM7, nib[r], (uint32_t)Uraw);
 									if constexpr (HASJ) nib[r] = (nib[r] & 15u) | (((uint32_t)Jraw & 8u) << 1);
 								}
 								if constexpr (MODE == K_LOCAL) {
@@ -421,12 +462,12 @@ __global__ __launch_bounds__(64) void at_sweep(const SweepArgs a)
 								up = Xo;
 								Mo_l[r] = Mo; U_l[r] = Uc;
 								if constexpr (KEEPL) L_l[r] = Lc;
-								if constexpr (HASJ) { Mg_l[r] = Mc + g16; J_l[r] = Jc; }
+								if constexpr (HASJ) { Mg_l[r] = Mc + g16v; J_l[r] = Jc; }
 							} else if constexpr (MODE == K_OVERLAP) {
 								/* max5(M(i,j-1)+o, M(i-1,j-1)+s, M(i-1,j)+o): LEFT, DIAGONAL, RIGHT  :944 */
 								const int old = Mo_l[r];
 								const int Mraw = imax3(old | 3, (diag + s16) | 2, up | 1);
-								const int P = (Mraw & ~15) + o16;
+								const int P = (Mraw & ~15) + o16v;
 								nib[r] = (uint32_t)Mraw;
 								Mo_l[r] = P; diag = old; up = P;
 							} else {
@@ -544,12 +585,40 @@ __global__ __launch_bounds__(64) void at_sweep(const SweepArgs a)
 				if ((cnt & 63) == 63) ops[cnt - 63 + lane] = (uint8_t)opreg;
 				++cnt;
 			};
+			/* Pointer cells are read through a register cache of one time-major block row: the K*NL words of
+			 * (strip, t/SPD) are one coalesced load (each lane keeps its own K words); the walk picks the word of
+			 * lane `ln` with v_readlane.  A path moves by at most 2 anti-diagonals per step, so a row serves >= SPD/2
+			 * steps, and the row below it (t decreasing) is prefetched while the current one is walked. */
+			uint32_t cw[K], cwn[K];
+			int ckey = -1, nkey = -1;       /* row index ss*wps/K + t/SPD currently in cw / cwn */
+			const int rows_per_strip = wps / K;
+			auto load_row = [&](int key, uint32_t (&dst)[K]) {
+				const int base = a.off_ptr + key * K * NL;
+#pragma unroll
+				for (int r = 0; r < K; ++r) dst[r] = lane < NL ? pm.ld(base + r * NL + lane) : 0u;
+			};
 			auto fetch = [&](int ii, int jj) -> uint32_t {
 				const int ss = (ii - 1) / RS, li = (ii - 1) % RS;
 				const int ln = li / K, r = li % K;
 				const int t = (jj - 1) + ln;
-				const uint32_t w = pm.ld(a.off_ptr + (ss * wps + (t / SPD) * K + r) * NL + ln);
-				return (uint32_t)uni((int)((w >> ((t % SPD) * PB)) & ((1u << PB) - 1u)));
+				const int key = ss * rows_per_strip + t / SPD;
+				if (key != ckey) {
+					if (key == nkey) {
+#pragma unroll
+						for (int q = 0; q < K; ++q) cw[q] = cwn[q];
+					} else {
+						load_row(key, cw);
+					}
+					ckey = key;
+					nkey = key - 1;
+					if (nkey >= 0) load_row(nkey, cwn);
+				}
+				uint32_t mine = cw[0];
+#pragma unroll
+				for (int q = 1; q < K; ++q)
+					if (r == q) mine = cw[q];
+				const uint32_t w = (uint32_t)__builtin_amdgcn_readlane((int)mine, ln);
+				return (w >> ((t % SPD) * PB)) & ((1u << PB) - 1u);
 			};
 			int guard = l1 + l2 + 2;
 			pm.ready();

@@ -77,19 +77,6 @@ AT_DEV uint32_t pneg(uint32_t a)
 {
 	return __builtin_bit_cast(uint32_t, __builtin_bit_cast(s16x2, a) >> (s16x2)(15));
 }
-/* v_bfi_b32 / v_and_or_b32 spelled out: hipcc otherwise re-associates the nested selects into longer and/or3 chains */
-AT_DEV uint32_t vbfi(uint32_t mask, uint32_t a, uint32_t b)
-{
-	uint32_t d;
-	asm("v_bfi_b32 %0, %1, %2, %3" : "=v"(d) : "v"(mask), "v"(a), "v"(b));
-	return d;
-}
-AT_DEV uint32_t vandor(uint32_t a, uint32_t m, uint32_t o)
-{
-	uint32_t d;
-	asm("v_and_or_b32 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(m), "v"(o));
-	return d;
-}
 AT_DEV int half(uint32_t v, int h) { return (int)(short)(h ? (v >> 16) : (v & 0xffffu)); }
 
 constexpr uint32_t kClean2 = 0xfff0fff0u, kTagL2 = 0x000f000fu, kTagM2 = 0x000a000au, kTagU2 = 0x00010001u;

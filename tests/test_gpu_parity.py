@@ -136,3 +136,89 @@ def test_packed16_uniform_batches_match_oracle(al, mode):
                 assert int(res["score"][k]) == r["score"], (mode, l1, l2, sc, k)
                 assert (int(res["end_i"][k]), int(res["end_j"][k]), int(res["state"][k])) == (r["end_i"], r["end_j"], r["state"]), (mode, l1, l2, sc, k)
                 assert res["ops"][k] == r["ops"], (mode, l1, l2, sc, k)
+
+
+def _rescore(ops, s1, s2, ei, ej, m, u, o, e, mode):
+    """Independent check: walk the ops (END->START) and add up the score the path implies."""
+    i, j, sc, prev = ei, ej, 0, None
+    for op in ops:
+        if op == 0:
+            i -= 1; j -= 1
+            sc += m if s1[i] == s2[j] else u
+        else:
+            if op == 1:
+                i -= 1
+            else:
+                j -= 1
+            sc += e if prev == op else o     # interior gap of length k costs o + e*(k-1)
+        prev = op
+    return sc, i, j
+
+
+def test_full_size_c2_batch_properties(al):
+    """BASELINE configs[1] at full size (100k x 150x150 local): size-independent properties on every pair
+    -- the ops string re-scores to the reported score, starts inside the matrix, ends in a HOME cell --
+    and bit-exact equality with the oracle on a seeded sample."""
+    from aligntools.c_amd.synth import synth_pairs_blob
+    n, l1, l2 = 100000, 150, 150
+    blob = synth_pairs_blob(0x5EED0002, n, l1, l2)
+    pairs = [(row[:l1].tobytes(), row[l1:].tobytes()) for row in blob]
+    al.set_scoring(2, -2, -5, -2)
+    res = al.align_batch("local", pairs, render=False)
+    assert "packed16" in al.last_config
+    assert (res["score"] >= 0).all() and (res["end_i"] >= 1).all() and (res["end_j"] <= l2).all()
+    bad = 0
+    for k in range(0, n, 7):
+        s1, s2 = pairs[k]
+        sc, i, j = _rescore(res["ops"][k], s1, s2, int(res["end_i"][k]), int(res["end_j"][k]), 2, -2, -5, -2, "local")
+        # the HOME cell is emitted as an aligned pair (SURVEY 0.6): its own contribution is clamped away
+        first = res["ops"][k][-1:]
+        home = (2 if s1[i] == s2[j] else -2) if first == b"\x00" else 0
+        if not (sc - home <= int(res["score"][k]) <= sc - min(home, 0)) or i < 0 or j < 0:
+            bad += 1
+    assert bad == 0
+    rng = random.Random(3)
+    for k in rng.sample(range(n), 300):
+        r = O.align(O.LOCAL, pairs[k][0], pairs[k][1], 2, -2, -5, -2)
+        assert (int(res["score"][k]), int(res["end_i"][k]), int(res["end_j"][k]), res["ops"][k]) == (r["score"], r["end_i"], r["end_j"], r["ops"])
+
+
+def test_edge_cases_empty_ragged_and_ranges(al):
+    import aligntools.c_amd as A
+    # empty sequences where the reference is defined: global pads, edit counts, overlap of an empty s1
+    al.set_scoring(1, -1, -4, -1)
+    res = al.align_batch("global", [("", "ACG"), ("AC", ""), ("", "")])
+    assert res["score"].tolist() == [-4 - 3, -4 - 2, 0]
+    assert (res["r1"], res["r2"]) == (["---", "AC", ""], ["ACG", "--", ""])
+    assert al.align_batch("edit", [("", "ACGT"), ("ACG", ""), ("", "")])["score"].tolist() == [4, 3, 0]
+    assert al.align_batch("overlap", [("", "ACGT")])["score"].tolist() == [0]
+    # outside the reference's domain: reported, not guessed
+    for mode, pair in (("local", ("", "ACG")), ("overlap", ("ACG", "")), ("fit", ("", "ACGT"))):
+        with pytest.raises(A.AlignToolsError) as ei:
+            al.align_batch(mode, [pair])
+        assert ei.value.code == -4
+    # ragged batch (int32 kernel), lengths straddling the 64*K strip edges, vs the oracle
+    rng = random.Random(11)
+    pairs = [("".join(rng.choice("ACGT") for _ in range(l1)), "".join(rng.choice("ACGT") for _ in range(l2)))
+             for l1, l2 in [(1, 1), (63, 300), (64, 1), (65, 129), (255, 256), (256, 255), (257, 40), (513, 700), (2, 1100)]]
+    al.set_scoring(2, -2, -5, -2)
+    for mode in ("global", "local", "overlap", "edit"):
+        res = al.align_batch(mode, pairs)
+        assert "int32" in al.last_config
+        for k, (a, b) in enumerate(pairs):
+            r = O.align(O.MODE_NAMES[mode], a, b, 2, -2, -5, -2)
+            assert int(res["score"][k]) == r["score"]
+            if mode != "edit":
+                assert res["ops"][k] == r["ops"]
+    # scores too large for the byte LUT of the 2-bit kernels -> 8-bit kernels, same answers
+    al.set_scoring(20, -30, -50, -10)
+    res = al.align_batch("local", pairs[:6])
+    assert "bits=8" in al.last_config
+    for k, (a, b) in enumerate(pairs[:6]):
+        r = O.align(O.LOCAL, a, b, 20, -30, -50, -10)
+        assert int(res["score"][k]) == r["score"] and res["ops"][k] == r["ops"]
+    # scores that could leave the exact integer range are refused
+    al.set_scoring(1 << 20, -(1 << 20), -5, -1)
+    with pytest.raises(A.AlignToolsError) as ei:
+        al.align_batch("global", pairs[:2])
+    assert ei.value.code == -3

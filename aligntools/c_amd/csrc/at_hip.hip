@@ -267,13 +267,14 @@ static Layout16 layout16_for(bool tb, int l1, int l2)
 		L.k = l1 <= 112 ? 7 : (l1 <= 160 ? 10 : 13);
 	}
 	const int ng = 64 / L.g;
-	const int tbk = (l2 + L.g - 1 + at::kBlk - 1) / at::kBlk;
+	const int blk = L.g == 16 ? 4 : 8;        /* BLK of at_sweep16 */
+	const int tbk = (l2 + L.g - 1 + blk - 1) / blk;
 	L.ptr_lanes = L.g == 64 ? std::max(1, std::min(64, (l1 + L.k - 1) / L.k)) : 64;
 	const long long nstrips = (l1 + L.g * L.k - 1) / (L.g * L.k);
-	long long nref = (at::kPad + (long long)tbk * at::kBlk) / 4 + 4;
+	long long nref = (at::kPad + (long long)tbk * blk) / 4 + 4;
 	nref = (nref + 1) & ~1LL;
 	const long long nbound = 2LL * (l2 + 2);
-	const long long nptr = tb ? nstrips * tbk * 2 * L.k * L.ptr_lanes + 64 : 0;
+	const long long nptr = tb ? nstrips * tbk * (blk / 4) * L.k * L.ptr_lanes + 64 : 0;
 	L.off_refb = (int)nref;
 	L.off_bound = (int)(2 * nref * ng);
 	L.off_ptr = (int)(2 * nref * ng + nbound);

@@ -128,6 +128,12 @@ __global__ __launch_bounds__(64, AT_WAVES16(G, K)) void at_sweep16(const Sweep16
 	static_assert(MODE == K_GLOBAL || MODE == K_LOCAL || MODE == K_FIT, "packed path: 3-state modes without the jump state");
 	static_assert(G == 64 || G == 16, "group width");
 	constexpr int NG = 64 / G;                /* groups per wavefront, 2 alignments each */
+	/* steps per unrolled block.  The 16-lane kernels carry 7..13 rows per lane, so 4 steps (one pointer word) already
+	 * unroll to ~6 KB of code and only one (masked) body is emitted: every launch starts with a cold instruction
+	 * cache, and at ~1 ms per launch the first pass through tens of KB of straight-line code is measurable. */
+	constexpr int BLK = G == 16 ? 4 : 8;
+	constexpr bool ONEBODY = G == 16;
+	constexpr int RPB = BLK / 4;              /* pointer word rows per block */
 	constexpr int RS = G * K;                 /* rows per strip (G < 64: the only strip) */
 	constexpr int PADW = kPad / 4;            /* s2 bytes: 4 per word */
 	const int lane = threadIdx.x;
@@ -148,8 +154,8 @@ __global__ __launch_bounds__(64, AT_WAVES16(G, K)) void at_sweep16(const Sweep16
 	asm volatile("" : "+v"(o2), "+v"(e2), "+v"(lut_lo), "+v"(lut_hi));
 	asm volatile("" : "+v"(cClean), "+v"(cTagM), "+v"(cTagL), "+v"(cTagU), "+v"(cM3), "+v"(cM7), "+v"(cNib));
 	const int nstrips = (l1 + RS - 1) / RS;   /* host guarantees 1 when G < 64 */
-	const int tbk = (l2 + G - 1 + kBlk - 1) / kBlk;
-	const int wps = tbk * 2 * K;              /* pointer word rows per strip: 4 steps per word */
+	const int tbk = (l2 + G - 1 + BLK - 1) / BLK;
+	const int wps = tbk * RPB * K;            /* pointer word rows per strip: 4 steps per word */
 	const int lastlane = l1 > 0 ? ((l1 - 1) % RS) / K : 0;   /* lane-in-group owning row l1 */
 	const int rl = l1 > 0 ? ((l1 - 1) % RS) % K : 0;
 	const long long nwork = (a.npairs + 2 * NG - 1) / (2 * NG);
@@ -237,18 +243,24 @@ __global__ __launch_bounds__(64, AT_WAVES16(G, K)) void at_sweep16(const Sweep16
 			const int ptr_base = a.off_ptr + s * wps * NL;
 
 			for (int blk = 0; blk < tbk; ++blk) {
-				const int t0 = blk * kBlk;
-				load_bound(t0 + kBlk, bxn, bln);
+				const int t0 = blk * BLK;
+				load_bound(t0 + BLK, bxn, bln);
 				/* ---- s2 windows: bytes t0-lg .. t0-lg+7 of both alignments ---- */
 				uint32_t wA[2], wB[2];
 				{
 					const int e0 = t0 - lg + kPad;
 					const int w = refoff + (e0 >> 2);
 					const int sh = (e0 & 3) * 8;
-					const uint32_t a0 = mem.ld(w), a1 = mem.ld(w + 1), a2 = mem.ld(w + 2);
-					const uint32_t b0 = mem.ld(a.off_refb + w), b1 = mem.ld(a.off_refb + w + 1), b2 = mem.ld(a.off_refb + w + 2);
-					wA[0] = __builtin_amdgcn_alignbit(a1, a0, sh); wA[1] = __builtin_amdgcn_alignbit(a2, a1, sh);
-					wB[0] = __builtin_amdgcn_alignbit(b1, b0, sh); wB[1] = __builtin_amdgcn_alignbit(b2, b1, sh);
+					const uint32_t a0 = mem.ld(w), a1 = mem.ld(w + 1);
+					const uint32_t b0 = mem.ld(a.off_refb + w), b1 = mem.ld(a.off_refb + w + 1);
+					wA[0] = __builtin_amdgcn_alignbit(a1, a0, sh);
+					wB[0] = __builtin_amdgcn_alignbit(b1, b0, sh);
+					wA[1] = 0; wB[1] = 0;
+					if constexpr (BLK == 8) {
+						const uint32_t a2 = mem.ld(w + 2), b2 = mem.ld(a.off_refb + w + 2);
+						wA[1] = __builtin_amdgcn_alignbit(a2, a1, sh);
+						wB[1] = __builtin_amdgcn_alignbit(b2, b1, sh);
+					}
 				}
 				const int jm1_0 = t0 - lg;
 
@@ -335,7 +347,7 @@ __global__ __launch_bounds__(64, AT_WAVES16(G, K)) void at_sweep16(const Sweep16
 					if constexpr (TB) {
 						if ((k & 3) == 3 && lane < NL) {
 #pragma unroll
-							for (int r = 0; r < K; ++r) pm.st(ptr_base + ((blk * 2 + hw) * K + r) * NL + lane, acc[r]);
+							for (int r = 0; r < K; ++r) pm.st(ptr_base + ((blk * RPB + hw) * K + r) * NL + lane, acc[r]);
 						}
 					}
 				};
@@ -344,9 +356,12 @@ __global__ __launch_bounds__(64, AT_WAVES16(G, K)) void at_sweep16(const Sweep16
 #define AT_STEPS16(M)                                                                                    \
 	step(std::integral_constant<int, 0>{}, M{}); step(std::integral_constant<int, 1>{}, M{});            \
 	step(std::integral_constant<int, 2>{}, M{}); step(std::integral_constant<int, 3>{}, M{});            \
-	step(std::integral_constant<int, 4>{}, M{}); step(std::integral_constant<int, 5>{}, M{});            \
-	step(std::integral_constant<int, 6>{}, M{}); step(std::integral_constant<int, 7>{}, M{});
-				if (t0 >= nl - 1 && t0 + kBlk <= l2) { AT_STEPS16(F) }
+	if constexpr (BLK == 8) {                                                                            \
+		step(std::integral_constant<int, 4>{}, M{}); step(std::integral_constant<int, 5>{}, M{});        \
+		step(std::integral_constant<int, 6>{}, M{}); step(std::integral_constant<int, 7>{}, M{});        \
+	}
+				if constexpr (ONEBODY) { AT_STEPS16(T) }
+				else if (t0 >= nl - 1 && t0 + BLK <= l2) { AT_STEPS16(F) }
 				else { AT_STEPS16(T) }
 #undef AT_STEPS16
 				bx = bxn; bl = bln;
@@ -369,12 +384,12 @@ __global__ __launch_bounds__(64, AT_WAVES16(G, K)) void at_sweep16(const Sweep16
 		}
 
 		pm.ready();
-		/* ================= per alignment: end cell, traceback, outputs ================= */
+		/* ================= end cells: lane gh receives the result of alignment gh = 2*group + half ================= */
+		int my_sc = 0, my_ci = 0, my_cj = 0, my_st = 2;
+		bool my_ok = true;
 #pragma unroll 1
 		for (int gh = 0; gh < 2 * NG; ++gh) {
 			const int g = gh >> 1, h = gh & 1;
-			const long long p = (wk * NG + g) * 2 + h;
-			if (p >= a.npairs) break;
 			const int glane = g * G;               /* lane 0 of the group */
 			int sc16 = 0, ci = 0, cj = 0, st = 2;
 			bool ok = true;
@@ -405,47 +420,48 @@ __global__ __launch_bounds__(64, AT_WAVES16(G, K)) void at_sweep16(const Sweep16
 				else { sc16 = bM; st = 2; cj = jM; }
 				ok = sc16 > a.thresh16;
 			}
-			int cnt = 0;
-			const int ei = ci, ej = cj, est = st;
-			if constexpr (TB) {
-				uint8_t *ops = a.ops + a.ops_off[p];
-				uint32_t opreg = 0;
-				auto emit = [&](int op) {
-					if (lane == (cnt & 63)) opreg = (uint32_t)op;
-					if ((cnt & 63) == 63) ops[cnt - 63 + lane] = (uint8_t)opreg;
-					++cnt;
-				};
-				auto fetch = [&](int ii, int jj) -> uint32_t {
-					const int ss = (ii - 1) / RS, li = (ii - 1) % RS;
-					const int ln = li / K, r = li % K;
-					const int t = (jj - 1) + ln;
-					const uint32_t w = pm.ld(a.off_ptr + (ss * wps + (t >> 2) * K + r) * NL + glane + ln);
-					return (uint32_t)uni((int)((w >> (16 * h + 4 * (3 - (t & 3)))) & 15u));
-				};
-				int guard = l1 + l2 + 2;
-				if (ok) {
-					while (ci > 0 && (MODE == K_FIT || cj > 0) && --guard >= 0) {
-						if (MODE == K_LOCAL && st == 0) break;
-						if (cj <= 0) { ok = false; break; }
-						const uint32_t nb = fetch(ci, cj);
-						if (st == 3) { st = (nb & 4u) ? 3 : 2; emit(1); --ci; }
-						else if (st == 2) { st = (int)(nb & 3u); emit(0); --ci; --cj; }
-						else if (st == 1) { st = (nb & 8u) ? 2 : 1; emit(2); --cj; }
-						else { ok = false; break; }
+			if (lane == gh) { my_sc = sc16; my_ci = ci; my_cj = cj; my_st = st; my_ok = ok; }
+		}
+		/* ================= tracebacks: the 2*NG pointer walks run side by side, one per lane, so their
+		 *                   dependent pointer loads overlap instead of queueing behind each other ================= */
+		{
+			const int g = lane >> 1, h = lane & 1;
+			const long long p = (wk * NG + g) * 2 + h;
+			const bool mine = lane < 2 * NG && p < a.npairs;
+			if (mine) {
+				int ci = my_ci, cj = my_cj, st = my_st, cnt = 0;
+				bool ok = my_ok;
+				if constexpr (TB) {
+					uint8_t *ops = a.ops + a.ops_off[p];
+					const int glane = g * G;
+					int guard = l1 + l2 + 2;
+					if (ok) {
+						while (ci > 0 && (MODE == K_FIT || cj > 0) && --guard >= 0) {
+							if (MODE == K_LOCAL && st == 0) break;            /* HOME :788-791 */
+							if (cj <= 0) { ok = false; break; }
+							const int ss = (ci - 1) / RS, li = (ci - 1) % RS;
+							const int ln = li / K, r = li % K;
+							const int t = (cj - 1) + ln;
+							const uint32_t w = pm.ld(a.off_ptr + (ss * wps + (t >> 2) * K + r) * NL + glane + ln);
+							const uint32_t nb = (w >> (16 * h + 4 * (3 - (t & 3)))) & 15u;
+							int op;
+							if (st == 3) { st = (nb & 4u) ? 3 : 2; op = 1; --ci; }
+							else if (st == 2) { st = (int)(nb & 3u); op = 0; --ci; --cj; }
+							else if (st == 1) { st = (nb & 8u) ? 2 : 1; op = 2; --cj; }
+							else { ok = false; break; }
+							ops[cnt++] = (uint8_t)op;
+						}
+						if constexpr (MODE == K_GLOBAL) {                     /* padding loops :398-407 */
+							while (cj > 0) { ops[cnt++] = 2; --cj; }
+							while (ci > 0) { ops[cnt++] = 1; --ci; }
+						}
+						if (guard < 0) ok = false;
 					}
-					if constexpr (MODE == K_GLOBAL) {
-						while (cj > 0) { emit(2); --cj; }
-						while (ci > 0) { emit(1); --ci; }
-					}
-					if (guard < 0) ok = false;
 				}
-				if ((cnt & 63) != 0 && lane < (cnt & 63)) ops[(cnt & ~63) + lane] = (uint8_t)opreg;
-			}
-			if (lane == 0) {
-				a.score[p] = ok ? (sc16 >> kShift) : INT32_MIN;
-				if (a.end_i) a.end_i[p] = ei;
-				if (a.end_j) a.end_j[p] = ej;
-				if (a.state) a.state[p] = est == 3 ? 1 : est == 2 ? 2 : 3;
+				a.score[p] = ok ? (my_sc >> kShift) : INT32_MIN;
+				if (a.end_i) a.end_i[p] = my_ci;
+				if (a.end_j) a.end_j[p] = my_cj;
+				if (a.state) a.state[p] = my_st == 3 ? 1 : my_st == 2 ? 2 : 3;
 				if (a.nops) a.nops[p] = ok ? cnt : -1;
 			}
 		}

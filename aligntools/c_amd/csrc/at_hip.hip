@@ -5,6 +5,7 @@
  * compute path: every DP cell is computed on the GPU or the call fails.
  */
 #include "at_launch.h"
+#include "at_pack.hip.h"
 #include "../../../include/aligntools_hip.h"
 
 #include <algorithm>
@@ -32,6 +33,7 @@ struct at_handle {
 	unsigned long long *d_queue = nullptr;
 	void *d_in = nullptr; size_t in_bytes = 0;
 	void *d_out = nullptr; size_t out_bytes = 0;
+	void *d_desc = nullptr; size_t desc_bytes = 0;
 	char err[512] = {0};
 	char cfg[160] = "none";
 };
@@ -97,6 +99,7 @@ extern "C" void at_destroy(at_handle *h)
 	if (h->d_queue) (void)hipFree(h->d_queue);
 	if (h->d_in) (void)hipFree(h->d_in);
 	if (h->d_out) (void)hipFree(h->d_out);
+	if (h->d_desc) (void)hipFree(h->d_desc);
 	if (h->stream) (void)hipStreamDestroy(h->stream);
 	delete h;
 }
@@ -520,43 +523,88 @@ extern "C" int at_align_batch(at_handle *h, int mode, int64_t npairs, const uint
 	}
 	HIP_TRY(h, hipSetDevice(h->device));
 
-	int bits = 0;
-	int rc = at_pack_batch(npairs, seq_blob, off1, len1, off2, len2, 0, &bits, nullptr, (int64_t *)off1 /*unused*/, (int64_t *)off2);
-	if (rc) return rc;
-	if (bits == 2 && !scores_fit_byte(h, mode)) bits = 8;   /* large scores: byte-compare kernels */
-	const int64_t nwords = at_pack_words(npairs, len1, len2, bits);
-	std::vector<uint32_t> words((size_t)nwords);
-	std::vector<int64_t> woff1((size_t)npairs), woff2((size_t)npairs);
-	rc = at_pack_batch(npairs, seq_blob, off1, len1, off2, len2, bits, nullptr, words.data(), woff1.data(), woff2.data());
-	if (rc) return rc;
-
-	/* device input block: words | woff1 | woff2 | len1 | len2 | ops_off */
+	/* ---- inputs go up RAW; packing happens on the GPU (at_pack.hip.h).  Host work is O(npairs): word offsets. ---- */
+	std::vector<int64_t> soff((size_t)2 * npairs), swoff2((size_t)2 * npairs), swoff8((size_t)2 * npairs);
+	std::vector<int32_t> slen((size_t)2 * npairs);
+	int64_t nwords2 = 0, nwords8 = 0, blob_bytes = 0;
+	for (int64_t k = 0; k < npairs; ++k) {
+		soff[2 * k] = off1[k]; slen[2 * k] = len1[k];
+		soff[2 * k + 1] = off2[k]; slen[2 * k + 1] = len2[k];
+		for (int q = 0; q < 2; ++q) {
+			const int len = slen[2 * k + q];
+			swoff2[2 * k + q] = nwords2; nwords2 += (len + 15) / 16 + 1;
+			swoff8[2 * k + q] = nwords8; nwords8 += (len + 3) / 4 + 1;
+			blob_bytes = std::max<int64_t>(blob_bytes, soff[2 * k + q] + len);
+		}
+	}
 	auto al = [](size_t x) { return (x + 255) & ~(size_t)255; };
-	const size_t b_words = al((size_t)nwords * 4), b_off = al((size_t)npairs * 8), b_len = al((size_t)npairs * 4);
-	const size_t in_need = b_words + 3 * b_off + 2 * b_len;
-	rc = grow(h, &h->d_in, &h->in_bytes, in_need);
+	const bool force8 = !scores_fit_byte(h, mode);    /* large scores: byte-compare kernels */
+	const int64_t nwords_max = std::max(nwords2, nwords8) + 4;
+	/* device input block: words | seq off | seq woff | seq len | ops_off | flag | raw blob */
+	const size_t b_words = al((size_t)nwords_max * 4), b_off = al((size_t)2 * npairs * 8), b_len = al((size_t)2 * npairs * 4);
+	const size_t b_blob = al((size_t)blob_bytes + 16);
+	const size_t in_need = b_words + 3 * b_off + b_len + 256 + b_blob;
+	int rc = grow(h, &h->d_in, &h->in_bytes, in_need);
 	if (rc) return rc;
 	char *din = (char *)h->d_in;
 	uint32_t *d_words = (uint32_t *)din;
-	int64_t *d_woff1 = (int64_t *)(din + b_words), *d_woff2 = (int64_t *)(din + b_words + b_off);
+	int64_t *d_soff = (int64_t *)(din + b_words), *d_swoff = (int64_t *)(din + b_words + b_off);
 	int64_t *d_opsoff = (int64_t *)(din + b_words + 2 * b_off);
-	int32_t *d_len1 = (int32_t *)(din + b_words + 3 * b_off), *d_len2 = (int32_t *)(din + b_words + 3 * b_off + b_len);
-	/* device output block: score | end_i | end_j | state | nops | ops */
-	const size_t out_need = 5 * b_len + al((size_t)ops_total + 64);
-	rc = grow(h, &h->d_out, &h->out_bytes, out_need);
-	if (rc) return rc;
-	char *dout = (char *)h->d_out;
-	int32_t *d_score = (int32_t *)dout, *d_ei = (int32_t *)(dout + b_len), *d_ej = (int32_t *)(dout + 2 * b_len);
-	int32_t *d_st = (int32_t *)(dout + 3 * b_len), *d_nops = (int32_t *)(dout + 4 * b_len);
-	uint8_t *d_ops = (uint8_t *)(dout + 5 * b_len);
-
+	int32_t *d_slen = (int32_t *)(din + b_words + 3 * b_off);
+	int *d_flag = (int *)(din + b_words + 3 * b_off + b_len);
+	uint8_t *d_blob = (uint8_t *)(din + b_words + 3 * b_off + b_len + 256);
 	hipStream_t s = h->stream;
-	HIP_TRY(h, hipMemcpyAsync(d_words, words.data(), (size_t)nwords * 4, hipMemcpyHostToDevice, s));
+	HIP_TRY(h, hipMemcpyAsync(d_blob, seq_blob, (size_t)blob_bytes, hipMemcpyHostToDevice, s));
+	HIP_TRY(h, hipMemcpyAsync(d_soff, soff.data(), (size_t)2 * npairs * 8, hipMemcpyHostToDevice, s));
+	HIP_TRY(h, hipMemcpyAsync(d_slen, slen.data(), (size_t)2 * npairs * 4, hipMemcpyHostToDevice, s));
+	if (tb) HIP_TRY(h, hipMemcpyAsync(d_opsoff, ops_off, (size_t)npairs * 8, hipMemcpyHostToDevice, s));
+	at::PackArgs pa;
+	pa.nseq = 2 * npairs; pa.blob = d_blob; pa.off = (const long long *)d_soff; pa.len = d_slen;
+	pa.woff = (const long long *)d_swoff; pa.words = d_words; pa.not_acgt = d_flag;
+	const unsigned pgrid = (unsigned)std::min<int64_t>((2 * npairs + 3) / 4, 8LL * h->ncu);
+	int bits = force8 ? 8 : 2;
+	int flag = 0;
+	if (bits == 2) {
+		HIP_TRY(h, hipMemsetAsync(d_flag, 0, 4, s));
+		HIP_TRY(h, hipMemcpyAsync(d_swoff, swoff2.data(), (size_t)2 * npairs * 8, hipMemcpyHostToDevice, s));
+		hipLaunchKernelGGL(at::at_pack<2>, dim3(pgrid), dim3(256), 0, s, pa);
+		HIP_TRY(h, hipMemcpyAsync(&flag, d_flag, 4, hipMemcpyDeviceToHost, s));
+		HIP_TRY(h, hipStreamSynchronize(s));
+		if (flag) bits = 8;                            /* some byte is not one of ACGT: byte kernels */
+	}
+	if (bits == 8) {
+		HIP_TRY(h, hipMemcpyAsync(d_swoff, swoff8.data(), (size_t)2 * npairs * 8, hipMemcpyHostToDevice, s));
+		hipLaunchKernelGGL(at::at_pack<8>, dim3(pgrid), dim3(256), 0, s, pa);
+	}
+	HIP_TRY(h, hipGetLastError());
+	/* the sweep kernels take per-pair arrays: views with stride 2 are not possible, so de-interleave on the host side
+	 * of the descriptor block (tiny) */
+	std::vector<int64_t> woff1((size_t)npairs), woff2((size_t)npairs);
+	{
+		const std::vector<int64_t> &sw = bits == 2 ? swoff2 : swoff8;
+		for (int64_t k = 0; k < npairs; ++k) { woff1[(size_t)k] = sw[2 * k]; woff2[(size_t)k] = sw[2 * k + 1]; }
+	}
+	const size_t b_poff = al((size_t)npairs * 8), b_plen = al((size_t)npairs * 4);
+	rc = grow(h, &h->d_desc, &h->desc_bytes, 2 * b_poff + 2 * b_plen);
+	if (rc) return rc;
+	char *dd = (char *)h->d_desc;
+	int64_t *d_woff1 = (int64_t *)dd, *d_woff2 = (int64_t *)(dd + b_poff);
+	int32_t *d_len1 = (int32_t *)(dd + 2 * b_poff), *d_len2 = (int32_t *)(dd + 2 * b_poff + b_plen);
 	HIP_TRY(h, hipMemcpyAsync(d_woff1, woff1.data(), (size_t)npairs * 8, hipMemcpyHostToDevice, s));
 	HIP_TRY(h, hipMemcpyAsync(d_woff2, woff2.data(), (size_t)npairs * 8, hipMemcpyHostToDevice, s));
 	HIP_TRY(h, hipMemcpyAsync(d_len1, len1, (size_t)npairs * 4, hipMemcpyHostToDevice, s));
 	HIP_TRY(h, hipMemcpyAsync(d_len2, len2, (size_t)npairs * 4, hipMemcpyHostToDevice, s));
-	if (tb) HIP_TRY(h, hipMemcpyAsync(d_opsoff, ops_off, (size_t)npairs * 8, hipMemcpyHostToDevice, s));
+	HIP_TRY(h, hipStreamSynchronize(s));   /* woff1/woff2 are stack-lifetime vectors */
+	const size_t b_len1 = al((size_t)npairs * 4);
+	/* device output block: score | end_i | end_j | state | nops | ops */
+	const size_t out_need = 5 * b_len1 + al((size_t)ops_total + 64);
+	rc = grow(h, &h->d_out, &h->out_bytes, out_need);
+	if (rc) return rc;
+	char *dout = (char *)h->d_out;
+	int32_t *d_score = (int32_t *)dout, *d_ei = (int32_t *)(dout + b_len1), *d_ej = (int32_t *)(dout + 2 * b_len1);
+	int32_t *d_st = (int32_t *)(dout + 3 * b_len1), *d_nops = (int32_t *)(dout + 4 * b_len1);
+	uint8_t *d_ops = (uint8_t *)(dout + 5 * b_len1);
+
 	rc = at_align_batch_device(h, mode, npairs, d_words, bits, d_woff1, d_len1, d_woff2, d_len2, max1, max2, uniform ? 1 : 0, tb ? 1 : 0,
 	                           d_score, d_ei, d_ej, d_st, tb ? d_ops : nullptr, tb ? d_opsoff : nullptr, tb ? d_nops : nullptr, s);
 	if (rc) return rc;

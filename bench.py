@@ -77,6 +77,7 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    use_dist = "RANK" in os.environ and "MASTER_ADDR" in os.environ   # launched by torch.distributed.run (any N)
     mode, l1, l2, pairs, scoring, use_jump, sites, seed = WORKLOADS[args.workload]
     if args.pairs:
         pairs = args.pairs
@@ -94,13 +95,13 @@ def main():
 
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
+    if use_dist:
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
     # ---- scoring block: rank 0 owns it, RCCL broadcast to the other ranks ----
     sc = torch.tensor(list(scoring) + [1 if use_jump else 0, len(sites)] + list(sites) + [0] * (16 - len(sites)),
                       dtype=torch.int32, device=dev)
-    if world > 1:
+    if use_dist:
         if rank != 0:
             sc.zero_()
         dist.broadcast(sc, src=0)
@@ -121,25 +122,27 @@ def main():
     d_len2 = torch.from_numpy(len2).to(dev)
     ops_off = np.arange(pairs, dtype=np.int64) * (l1 + l2)
     d_ops_off = torch.from_numpy(ops_off).to(dev)
-    d_res = torch.zeros((4, pairs), dtype=torch.int32, device=dev)     # score, end_i, end_j, state
+    # score, end_i, end_j, state -- two buffers: step k+1 must not overwrite what step k's all_gather still reads
+    d_res2 = [torch.zeros((4, pairs), dtype=torch.int32, device=dev) for _ in range(2)]
     d_nops = torch.zeros(pairs, dtype=torch.int32, device=dev)
     d_ops = torch.zeros(pairs * (l1 + l2) + 64, dtype=torch.uint8, device=dev) if tb else None
-    gathered = [torch.empty((world * 4, pairs), dtype=torch.int32, device=dev) for _ in range(2)] if world > 1 else None
+    gathered = [torch.empty((world * 4, pairs), dtype=torch.int32, device=dev) for _ in range(2)] if use_dist else None
 
     def step(k):
+        d_res = d_res2[k & 1]
         stream = torch.cuda.current_stream().cuda_stream
         al.align_batch_device(A.MODES[mode], pairs, d_words.data_ptr(), bits, d_woff1.data_ptr(), d_len1.data_ptr(),
                               d_woff2.data_ptr(), d_len2.data_ptr(), l1, l2, True, tb,
                               d_res[0].data_ptr(), d_res[1].data_ptr(), d_res[2].data_ptr(), d_res[3].data_ptr(),
                               d_ops.data_ptr() if tb else None, d_ops_off.data_ptr() if tb else None,
                               d_nops.data_ptr() if tb else None, stream)
-        if world > 1:   # gather the fixed-size results of this step; overlaps the next step's kernel
+        if use_dist:   # gather the fixed-size results of this step; overlaps the next step's kernel
             return dist.all_gather_into_tensor(gathered[k & 1], d_res, async_op=True)
         return None
 
     def sync_all():
         torch.cuda.synchronize()
-        if world > 1:
+        if use_dist:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -164,14 +167,14 @@ def main():
     sync_all()
     t1 = time.perf_counter()
     elapsed = torch.tensor([t1 - t0], dtype=torch.float64, device=dev)
-    if world > 1:
+    if use_dist:
         dist.all_reduce(elapsed, op=dist.ReduceOp.MAX)
     elapsed = float(elapsed.item())
 
     # ---- checks + accounting (outside the timed region) ----
     kern_ms = sorted(a.elapsed_time(b) for a, b in evs)
     kern_avg_ms = sum(kern_ms) / len(kern_ms)
-    scores = d_res[0].cpu().numpy()
+    scores = d_res2[(args.steps - 1) & 1][0].cpu().numpy()
     nops = d_nops.cpu().numpy() if tb else np.zeros(pairs, dtype=np.int32)
     assert (scores > -(1 << 30)).all() and (nops >= 0).all(), "kernel reported a domain error"
     cells_per_step = float(pairs) * l1 * l2 * world
@@ -209,7 +212,7 @@ def main():
             "cpu_baseline": base,
         }
         print(json.dumps(out))
-    if world > 1:
+    if use_dist:
         dist.destroy_process_group()
 
 

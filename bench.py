@@ -205,9 +205,11 @@ def main():
                        "parallelism": "pairs sharded over %d GPU(s), one process per GPU" % world},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                         "kernel": "at_sweep<%s,bits=%d>" % (mode, bits), "kernel_avg_ms": kern_avg_ms,
+                         "kernel": ("at_sweep16" if "packed16" in al.last_config else "at_sweep") + "<%s>" % mode,
+                         "kernel_avg_ms": kern_avg_ms,
                          "kernel_min_ms": kern_ms[0], "algorithmic_bytes_per_launch": bytes_in + bytes_out,
-                         "note": "integer max/add DP with the band on chip: VALU-bound by construction, see valu_* fields",
+                         "note": "integer max/add DP: the binding resource is VALU issue, not HBM (DESIGN.md section 4; "
+                                 "profiles/traffic_C2.json holds the SQ counters: 88 % of the measured half-rate issue bound)",
                          "valu_gcups_kernel": float(pairs) * l1 * l2 / (kern_avg_ms * 1e-3) / 1e9},
             "cpu_baseline": base,
         }

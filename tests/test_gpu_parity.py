@@ -222,3 +222,33 @@ def test_edge_cases_empty_ragged_and_ranges(al):
     with pytest.raises(A.AlignToolsError) as ei:
         al.align_batch("global", pairs[:2])
     assert ei.value.code == -3
+
+
+@pytest.mark.parametrize("mode", ["local", "global", "fit"])
+def test_packed16_score_range_extremes(al, mode):
+    """The packed kernel keeps 16*score in int16 with a -32768 sentinel: drive it to the edges of the
+    range the host admits -- all-mismatch and all-match pairs, one-sided gaps, the largest eligible
+    shape (two strips of 4 rows per lane) -- and require exact agreement with the fp64 oracle."""
+    rng = random.Random(2026)
+    for (l1, l2) in [(150, 150), (200, 208), (330, 330), (100, 500)]:
+        if mode != "fit" and (l1, l2) == (100, 500):
+            continue
+        a_run, c_run = "A" * l1, "C" * l2
+        rnd1 = "".join(rng.choice("ACGT") for _ in range(l1))
+        pairs = [(a_run, c_run),                                   # nothing matches: deepest negatives
+                 (a_run, ("A" * l2)),                              # everything matches: highest positives
+                 (rnd1, (rnd1 * 4)[:l2]),                          # long exact diagonals
+                 (rnd1, (rnd1[l1 // 2:] + rnd1 * 4)[:l2]),         # a long gap first
+                 ("AC" * (l1 // 2) + "A" * (l1 % 2), ("CA" * l2)[:l2]),   # tie-heavy periodic
+                 (a_run, ("C" * (l2 // 2) + "A" * l2)[:l2])]
+        for sc in ((2, -2, -5, -2), (1, -2, -5, -1)):
+            al.set_scoring(*sc)
+            res = al.align_batch(mode, pairs)
+            if "packed16" not in al.last_config:                  # shape/scoring not admitted: nothing to test here
+                continue
+            for k, (s1, s2) in enumerate(pairs):
+                r = O.align(O.MODE_NAMES[mode], s1, s2, *sc)
+                assert r["rc"] == 0
+                assert int(res["score"][k]) == r["score"], (mode, l1, l2, sc, k)
+                assert (int(res["end_i"][k]), int(res["end_j"][k]), int(res["state"][k])) == (r["end_i"], r["end_j"], r["state"]), (mode, l1, l2, sc, k)
+                assert res["ops"][k] == r["ops"], (mode, l1, l2, sc, k)

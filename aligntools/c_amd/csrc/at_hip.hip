@@ -259,7 +259,7 @@ struct Layout16 {
 
 /* Group width: reads of 97..208 bases run as 4 groups of 16 lanes x K rows (8 alignments per wave, 85 % of the
  * lane-steps inside a 150 x 150 matrix instead of 59 %); everything else as one group of 64 lanes. */
-static Layout16 layout16_for(bool tb, int l1, int l2)
+static Layout16 layout16_for(bool tb, bool hasj, int l1, int l2)
 {
 	Layout16 L;
 	const long long g_forced = env_ll("AT_GROUP", 0);
@@ -277,7 +277,7 @@ static Layout16 layout16_for(bool tb, int l1, int l2)
 	long long nref = (at::kPad + (long long)tbk * blk) / 4 + 4;
 	nref = (nref + 1) & ~1LL;
 	const long long nbound = 2LL * (l2 + 2);
-	const long long nptr = tb ? nstrips * tbk * (blk / 4) * L.k * L.ptr_lanes + 64 : 0;
+	const long long nptr = tb ? nstrips * tbk * (blk / (hasj ? 2 : 4)) * L.k * L.ptr_lanes + 64 : 0;
 	L.off_refb = (int)nref;
 	L.off_bound = (int)(2 * nref * ng);
 	L.off_ptr = (int)(2 * nref * ng + nbound);
@@ -292,10 +292,12 @@ static bool packed_ok(const at_handle *h, int mode, int bits, int l1, int l2, in
 {
 	if (getenv("AT_NO_PACKED") && atoi(getenv("AT_NO_PACKED"))) return false;
 	if (bits != 2 || l1 < 1 || l2 < 1) return false;
-	if (!(mode == AT_MODE_GLOBAL || mode == AT_MODE_LOCAL || (mode == AT_MODE_FIT && !h->use_jump))) return false;
+	if (!(mode == AT_MODE_GLOBAL || mode == AT_MODE_LOCAL || mode == AT_MODE_FIT)) return false;
 	if (h->m < 0 || h->u > 0 || h->o > 0 || h->e > 0) return false;
+	const bool hasj = mode == AT_MODE_FIT && h->use_jump;
+	if (hasj && (h->j > 0 || std::llabs((long long)h->j - h->o) * 16 > 32000)) return false;
 	const long long A = std::max<long long>(std::max(std::llabs((long long)h->e), std::llabs((long long)h->u)), h->m);
-	const long long lo = 3 * std::llabs((long long)h->o) + A * ((long long)l1 + l2) + 16;
+	const long long lo = 3 * std::llabs((long long)h->o) + (hasj ? std::llabs((long long)h->j) : 0) + A * ((long long)l1 + l2) + 16;
 	const long long hi = (long long)h->m * std::min(l1, l2);
 	const long long slack = std::llabs((long long)h->o) + std::llabs((long long)h->e) + 3;
 	if (16 * (lo + hi + slack) >= 32768) return false;
@@ -435,13 +437,18 @@ extern "C" int at_align_batch_device(at_handle *h, int mode, int64_t npairs,
 	/* ---- packed int16 path: uniform shape, scores provably within 16 bits ---- */
 	int thresh16 = 0;
 	if (uniform_shape && packed_ok(h, mode, bits, max_len1, max_len2, &thresh16)) {
-		const Layout16 P = layout16_for(tb, max_len1, max_len2);
+		const Layout16 P = layout16_for(tb, kmode == at::K_FITJ, max_len1, max_len2);
 		Sweep16Args b;
 		memset(&b, 0, sizeof b);
 		b.npairs = npairs; b.seq = d_seq;
 		b.woff1 = (const long long *)d_woff1; b.woff2 = (const long long *)d_woff2;
 		b.l1 = max_len1; b.l2 = max_len2;
-		b.m16 = h->m * 16; b.u16 = h->u * 16; b.o16 = h->o * 16; b.e16 = h->e * 16; b.thresh16 = thresh16;
+		b.m16 = h->m * 16; b.u16 = h->u * 16; b.o16 = h->o * 16; b.e16 = h->e * 16; b.g16 = h->j * 16; b.thresh16 = thresh16;
+		if (kmode == at::K_FITJ) {
+			int rcs = ensure_sitemask(h, max_len2, stream);
+			if (rcs) return rcs;
+			b.sitemask = h->d_sitemask;
+		}
 		b.score = d_score; b.end_i = d_end_i; b.end_j = d_end_j; b.state = d_state;
 		b.ops = d_ops; b.ops_off = (const long long *)d_ops_off; b.nops = d_nops;
 		b.off_refb = P.off_refb; b.off_bound = P.off_bound; b.ptr_lanes = P.ptr_lanes;

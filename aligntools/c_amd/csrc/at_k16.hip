@@ -30,6 +30,7 @@ at_sweep16_fn at_pick16(int kmode, int g, int k, int store, bool tb)
 	switch (kmode) {
 	case at::K_GLOBAL: return p2<at::K_GLOBAL>(g, k, store, tb);
 	case at::K_LOCAL: return p2<at::K_LOCAL>(g, k, store, tb);
+	case at::K_FITJ: return p2<at::K_FITJ>(g, k, store, tb);
 	default: return p2<at::K_FIT>(g, k, store, tb);
 	}
 }

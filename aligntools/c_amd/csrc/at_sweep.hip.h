@@ -209,14 +209,13 @@ AT_DEV int xo_of(int L, int M, int U, int J)
 	return x;
 }
 
-template <int K>
-AT_DEV int pick(const int (&v)[K], int r)   /* r is wave-uniform */
+/* v[r] for a wave-uniform r, written so that every array index is a compile-time constant: a variable index
+ * (even inside a loop that is later unrolled) makes hipcc keep the whole register array in scratch memory. */
+template <int K, int Q = 0, typename T>
+AT_DEV T pick(const T (&v)[K], int r)
 {
-	int x = v[0];
-#pragma unroll
-	for (int q = 1; q < K; ++q)
-		if (r == q) x = v[q];
-	return x;
+	if constexpr (Q == K - 1) return v[Q];
+	else return r == Q ? v[Q] : pick<K, Q + 1, T>(v, r);
 }
 
 template <int MODE, int BITS, int K, bool SMALL, bool PTRLDS, bool TB>
@@ -613,10 +612,7 @@ __global__ __launch_bounds__(64) void at_sweep(const SweepArgs a)
 					nkey = key - 1;
 					if (nkey >= 0) load_row(nkey, cwn);
 				}
-				uint32_t mine = cw[0];
-#pragma unroll
-				for (int q = 1; q < K; ++q)
-					if (r == q) mine = cw[q];
+				const uint32_t mine = pick<K>(cw, r);
 				const uint32_t w = (uint32_t)__builtin_amdgcn_readlane((int)mine, ln);
 				return (w >> ((t % SPD) * PB)) & ((1u << PB) - 1u);
 			};

@@ -41,7 +41,8 @@ struct Sweep16Args {
 	const long long *woff1;
 	const long long *woff2;
 	int l1, l2;                    /* uniform shape of the whole batch                    */
-	int m16, u16, o16, e16;        /* scores * 16 (each fits int16)                       */
+	int m16, u16, o16, e16, g16;   /* scores * 16 (each fits int16); g16: jump penalty    */
+	const uint32_t *sitemask;      /* fit -s: bit (j + 64) set = M->J may open at column j */
 	int thresh16;                  /* values <= thresh16 are "-inf" (fit end-cell scan)   */
 	int *score, *end_i, *end_j, *state;
 	uint8_t *ops;
@@ -72,6 +73,10 @@ AT_DEV uint32_t pshl4(uint32_t a)
 {
 	return __builtin_bit_cast(uint32_t, __builtin_bit_cast(s16x2, a) << (s16x2)(4));
 }
+AT_DEV uint32_t pshl8(uint32_t a)
+{
+	return __builtin_bit_cast(uint32_t, __builtin_bit_cast(s16x2, a) << (s16x2)(8));
+}
 /* 0xffff in every half that is negative */
 AT_DEV uint32_t pneg(uint32_t a)
 {
@@ -99,16 +104,6 @@ AT_DEV void border16(int i, int j, int o16, int e16, int &L, int &M, int &U)
 }
 AT_DEV int sat16(int v) { return v < -32768 ? -32768 : (v > 32767 ? 32767 : v); }
 
-template <int K>
-AT_DEV uint32_t pick(const uint32_t (&v)[K], int r)
-{
-	uint32_t x = v[0];
-#pragma unroll
-	for (int q = 1; q < K; ++q)
-		if (r == q) x = v[q];
-	return x;
-}
-
 /* second __launch_bounds__ argument = waves per SIMD the register allocator must leave room for */
 #ifndef AT_WAVES16
 #define AT_WAVES16(G, K) ((G) == 16 && (K) >= 10 ? 3 : 1)
@@ -125,7 +120,11 @@ AT_DEV uint32_t grp_up1(uint32_t old, uint32_t src)
 template <int MODE, int G, int K, bool SMALL, bool PTRLDS, bool TB>
 __global__ __launch_bounds__(64, AT_WAVES16(G, K)) void at_sweep16(const Sweep16Args a)
 {
-	static_assert(MODE == K_GLOBAL || MODE == K_LOCAL || MODE == K_FIT, "packed path: 3-state modes without the jump state");
+	static_assert(MODE == K_GLOBAL || MODE == K_LOCAL || MODE == K_FIT || MODE == K_FITJ, "packed path: the affine modes");
+	constexpr bool HASJ = MODE == K_FITJ;
+	constexpr bool ISFIT = MODE == K_FIT || MODE == K_FITJ;
+	constexpr int PB = HASJ ? 8 : 4;          /* pointer bits per cell and alignment */
+	constexpr int SPW = 16 / PB;              /* steps per pointer word (each half holds its own alignment) */
 	static_assert(G == 64 || G == 16, "group width");
 	constexpr int NG = 64 / G;                /* groups per wavefront, 2 alignments each */
 	/* steps per unrolled block.  The 16-lane kernels carry 7..13 rows per lane, so 4 steps (one pointer word) already
@@ -133,7 +132,7 @@ __global__ __launch_bounds__(64, AT_WAVES16(G, K)) void at_sweep16(const Sweep16
 	 * cache, and at ~1 ms per launch the first pass through tens of KB of straight-line code is measurable. */
 	constexpr int BLK = G == 16 ? 4 : 8;
 	constexpr bool ONEBODY = G == 16;
-	constexpr int RPB = BLK / 4;              /* pointer word rows per block */
+	constexpr int RPB = BLK / SPW;            /* pointer word rows per block */
 	constexpr int RS = G * K;                 /* rows per strip (G < 64: the only strip) */
 	constexpr int PADW = kPad / 4;            /* s2 bytes: 4 per word */
 	const int lane = threadIdx.x;
@@ -150,12 +149,16 @@ __global__ __launch_bounds__(64, AT_WAVES16(G, K)) void at_sweep16(const Sweep16
 	uint32_t lut_hi = (((uint32_t)a.m16 >> 8) & 0xffu) | ((((uint32_t)a.u16 >> 8) & 0xffu) * 0x01010100u);
 	/* constants live in VGPRs: VOP3 encodings take no 32-bit literals, and a literal would split and_or into two ops */
 	uint32_t cClean = kClean2, cTagM = kTagM2, cTagL = kTagL2, cTagU = kTagU2;
-	uint32_t cM3 = 0x00030003u, cM7 = 0x00070007u, cNib = 0x000f000fu;
+	uint32_t cM3 = 0x00030003u, cM7 = 0x00070007u, cNib = 0x000f000fu, c8 = 0x00080008u;
+	/* jump state: J(i,j) = max(M(i,j-1) + g, J(i,j-1)) where the column may open, else J(i,j-1) (alignment.h:658-666);
+	 * the left state holds M + o, so the opening candidate is (M + o) + (g - o), or -inf where opening is barred */
+	uint32_t gmo2 = pk2(a.g16 - a.o16), neg2 = 0x80008000u;
+	asm volatile("" : "+v"(c8), "+v"(gmo2), "+v"(neg2));
 	asm volatile("" : "+v"(o2), "+v"(e2), "+v"(lut_lo), "+v"(lut_hi));
 	asm volatile("" : "+v"(cClean), "+v"(cTagM), "+v"(cTagL), "+v"(cTagU), "+v"(cM3), "+v"(cM7), "+v"(cNib));
 	const int nstrips = (l1 + RS - 1) / RS;   /* host guarantees 1 when G < 64 */
 	const int tbk = (l2 + G - 1 + BLK - 1) / BLK;
-	const int wps = tbk * RPB * K;            /* pointer word rows per strip: 4 steps per word */
+	const int wps = tbk * RPB * K;            /* pointer word rows per strip */
 	const int lastlane = l1 > 0 ? ((l1 - 1) % RS) / K : 0;   /* lane-in-group owning row l1 */
 	const int rl = l1 > 0 ? ((l1 - 1) % RS) % K : 0;
 	const long long nwork = (a.npairs + 2 * NG - 1) / (2 * NG);
@@ -197,7 +200,7 @@ __global__ __launch_bounds__(64, AT_WAVES16(G, K)) void at_sweep16(const Sweep16
 		/* running results, per half */
 		int gbi[2] = {INT32_MAX, INT32_MAX}, gbj[2] = {INT32_MAX, INT32_MAX}, gbs[2] = {INT32_MIN, INT32_MIN};
 		uint32_t bestM = pk2(a.thresh16), bestMj = 0, bestL = pk2(a.thresh16), bestLj = 0;   /* fit scans */
-		uint32_t Mo_l[K], U_l[K], Xl[K], L_l[K];
+		uint32_t Mo_l[K], U_l[K], Xl[K], L_l[K], J_l[K];
 
 		for (int s = 0; s < nstrips; ++s) {
 			const int base = s * RS;
@@ -223,6 +226,7 @@ __global__ __launch_bounds__(64, AT_WAVES16(G, K)) void at_sweep16(const Sweep16
 				Mo_l[r] = pk2(sat16((M | kTagM) + o16));
 				U_l[r] = pk2(U | kTagU);
 				L_l[r] = pk2(L | kTagL);
+				J_l[r] = neg2;                    /* J is -inf on both borders (:616, :622) */
 				Xl[r] = pk2(imax3(L | kTagL, M | kTagM, U | kTagU));
 			}
 			uint32_t A_prev = Xl[K - 1], B_prev = 0, Ad;
@@ -262,6 +266,12 @@ __global__ __launch_bounds__(64, AT_WAVES16(G, K)) void at_sweep16(const Sweep16
 						wB[1] = __builtin_amdgcn_alignbit(b2, b1, sh);
 					}
 				}
+				uint32_t sm = 0;
+				if constexpr (HASJ) {
+					const int e0 = t0 - lg + 1 + 64;
+					const uint32_t w0 = a.sitemask[e0 >> 5], w1 = a.sitemask[(e0 >> 5) + 1];
+					sm = __builtin_amdgcn_alignbit(w1, w0, e0 & 31);
+				}
 				const int jm1_0 = t0 - lg;
 
 				auto step = [&](auto KC, auto MASKED) {
@@ -279,7 +289,9 @@ __global__ __launch_bounds__(64, AT_WAVES16(G, K)) void at_sweep16(const Sweep16
 					bool active = true;
 					if constexpr (masked) active = lg < nl && (unsigned)jm1 < (unsigned)l2;
 					if (active) {
-						if constexpr (MODE == K_FIT) {
+						uint32_t gopen = neg2;
+						if constexpr (HASJ) gopen = ((sm >> k) & 1u) ? gmo2 : neg2;
+						if constexpr (ISFIT) {
 							/* end-cell scan of row l1, columns 0..l2-1 (:676-690), one column behind the sweep;
 							 * every lane scans its own row rl, only the owner of row l1 is read at the end */
 							if (laststrip) {
@@ -308,13 +320,26 @@ __global__ __launch_bounds__(64, AT_WAVES16(G, K)) void at_sweep16(const Sweep16
 							const uint32_t Uraw = pmax(Mo_l[r], padd(U_l[r], e2));
 							const uint32_t Uc = vandor(Uraw, cClean, cTagU);
 							const uint32_t Mo = padd(Mc, o2);
-							const uint32_t Xo = pmax(pmax(Lc, Mc), Uc);
+							uint32_t Xo = pmax(pmax(Lc, Mc), Uc);
+							uint32_t Jraw = 0;
+							if constexpr (HASJ) {
+								Jraw = pmax(padd(Mo_l[r], gopen), J_l[r]);     /* M first: tag 10 beats J's tag 0 on ties */
+								const uint32_t Jc = Jraw & cClean;
+								Xo = pmax(Xo, Jc);
+								J_l[r] = Jc;
+							}
 							const uint32_t Ld = pmax(padd(Lc, e2), Mo);
 							if constexpr (TB) {
 								uint32_t nib = vbfi(cM3, Mraw, lraw);
 								nib = vbfi(cM7, nib, Uraw);
-								/* each half keeps its own 4-step shift register: acc = acc << 4 | nibble */
-								acc[r] = vandor(nib, cNib, pshl4(acc[r]));
+								if constexpr (HASJ) {
+									/* 5 bits: the nibble plus bit 4 = J came from M; two steps per 16-bit half */
+									nib = ((Jraw & c8) << 1) | (nib & cNib);
+									acc[r] = pshl8(acc[r]) | nib;
+								} else {
+									/* each half keeps its own 4-step shift register: acc = acc << 4 | nibble */
+									acc[r] = vandor(nib, cNib, pshl4(acc[r]));
+								}
 							}
 							if constexpr (MODE == K_LOCAL) {
 								uint32_t rt = (uint32_t)(K - 1 - r) * 0x00010001u;
@@ -341,13 +366,13 @@ __global__ __launch_bounds__(64, AT_WAVES16(G, K)) void at_sweep16(const Sweep16
 					else if constexpr (TB && masked) {
 						/* keep the shift registers in step: nibble k of a word is always step k of its 4-step group */
 #pragma unroll
-						for (int r = 0; r < K; ++r) acc[r] = pshl4(acc[r]);
+						for (int r = 0; r < K; ++r) acc[r] = HASJ ? pshl8(acc[r]) : pshl4(acc[r]);
 					}
 					Ad = Aup;
 					if constexpr (TB) {
-						if ((k & 3) == 3 && lane < NL) {
+						if ((k + 1) % SPW == 0 && lane < NL) {
 #pragma unroll
-							for (int r = 0; r < K; ++r) pm.st(ptr_base + ((blk * RPB + hw) * K + r) * NL + lane, acc[r]);
+							for (int r = 0; r < K; ++r) pm.st(ptr_base + ((blk * RPB + k / SPW) * K + r) * NL + lane, acc[r]);
 						}
 					}
 				};
@@ -436,18 +461,19 @@ __global__ __launch_bounds__(64, AT_WAVES16(G, K)) void at_sweep16(const Sweep16
 					const int glane = g * G;
 					int guard = l1 + l2 + 2;
 					if (ok) {
-						while (ci > 0 && (MODE == K_FIT || cj > 0) && --guard >= 0) {
+						while (ci > 0 && (ISFIT || cj > 0) && --guard >= 0) {
 							if (MODE == K_LOCAL && st == 0) break;            /* HOME :788-791 */
 							if (cj <= 0) { ok = false; break; }
 							const int ss = (ci - 1) / RS, li = (ci - 1) % RS;
 							const int ln = li / K, r = li % K;
 							const int t = (cj - 1) + ln;
-							const uint32_t w = pm.ld(a.off_ptr + (ss * wps + (t >> 2) * K + r) * NL + glane + ln);
-							const uint32_t nb = (w >> (16 * h + 4 * (3 - (t & 3)))) & 15u;
+							const uint32_t w = pm.ld(a.off_ptr + (ss * wps + (t / SPW) * K + r) * NL + glane + ln);
+							const uint32_t nb = (w >> (16 * h + PB * (SPW - 1 - (t % SPW)))) & ((1u << PB) - 1u);
 							int op;
 							if (st == 3) { st = (nb & 4u) ? 3 : 2; op = 1; --ci; }
 							else if (st == 2) { st = (int)(nb & 3u); op = 0; --ci; --cj; }
 							else if (st == 1) { st = (nb & 8u) ? 2 : 1; op = 2; --cj; }
+							else if (HASJ) { st = (nb & 16u) ? 2 : 0; op = 3; --cj; }       /* jump state :579-583 */
 							else { ok = false; break; }
 							ops[cnt++] = (uint8_t)op;
 						}

@@ -98,16 +98,20 @@ def test_reference_named_surface(al):
     assert "first sequence must be shorter" in str(ei.value)
 
 
-@pytest.mark.parametrize("mode", ["local", "global", "fit"])
+@pytest.mark.parametrize("mode", ["local", "global", "fit", "fitj"])
 def test_packed16_uniform_batches_match_oracle(al, mode):
     """Uniform-shape DNA batches take the packed two-pairs-per-wave kernel; every score,
     end cell, start state and ops string must equal the oracle's (odd batch sizes,
     1..4 rows per lane, two strips, related pairs with long tracebacks)."""
     rng = random.Random(77)
     shapes = [(150, 150), (40, 90), (100, 64), (130, 200), (250, 260), (300, 320), (1, 5), (64, 64), (65, 8)]
+    use_jump = mode == "fitj"
+    if use_jump:
+        mode = "fit"
     for (l1, l2) in shapes:
         if mode == "fit" and l1 > l2:
             continue
+        sites = sorted(rng.sample(range(l2 + 3), min(5, l2))) if use_jump else []
         for sc in ((2, -2, -5, -2), (1, -1, -1, -1), (1, -2, -5, -1), (0, 0, 0, 0)):
             n = rng.choice([1, 2, 7, 33])
             pairs = []
@@ -127,11 +131,12 @@ def test_packed16_uniform_batches_match_oracle(al, mode):
                     s2 = ("".join(rng.choice("ACGT") for _ in range(rng.randint(0, 6))) + "".join(body))
                     s2 = (s2 + "".join(rng.choice("ACGT") for _ in range(l2)))[:l2]
                 pairs.append((s1, s2))
-            al.set_scoring(*sc)
+            jp = rng.choice([-10, -3, 0])
+            al.set_scoring(*sc, jp, use_jump, sites)
             res = al.align_batch(mode, pairs)
             assert "packed16" in al.last_config, al.last_config
             for k, (s1, s2) in enumerate(pairs):
-                r = O.align(O.MODE_NAMES[mode], s1, s2, *sc)
+                r = O.align(O.MODE_NAMES[mode], s1, s2, *sc, jp, use_jump, sites)
                 assert r["rc"] == 0
                 assert int(res["score"][k]) == r["score"], (mode, l1, l2, sc, k)
                 assert (int(res["end_i"][k]), int(res["end_j"][k]), int(res["state"][k])) == (r["end_i"], r["end_j"], r["state"]), (mode, l1, l2, sc, k)

@@ -208,7 +208,7 @@ static long long env_ll(const char *name, long long dflt)
 }
 
 struct Layout {
-	int off_bound, off_ptr, k, ptr_lanes;
+	int off_bound, off_ptr, off_sm, nsm, k, ptr_lanes;
 	long long words;
 };
 
@@ -234,9 +234,12 @@ static Layout layout_for(int kmode, int bits, bool tb, int max_l1, int max_l2)
 	nref = (nref + 1) & ~1LL;
 	const long long nbound = 2LL * (max_l2 + 2);
 	const long long nptr = (tb && kmode != at::K_EDIT) ? nstrips * tbk * rpb * L.k * L.ptr_lanes + 64 : 0;
+	const long long nsm = kmode == at::K_FITJ ? (((long long)max_l2 + 64 + 64 + 128 + 31) / 32 + 2 + 1) & ~1LL : 0;
 	L.off_bound = (int)nref;
-	L.off_ptr = (int)(nref + nbound);
-	L.words = nref + nbound + nptr;
+	L.off_sm = (int)(nref + nbound);
+	L.nsm = (int)nsm;
+	L.off_ptr = (int)(nref + nbound + nsm);
+	L.words = nref + nbound + nsm + nptr;
 	return L;
 }
 
@@ -253,7 +256,7 @@ static bool scores_fit_byte(const at_handle *h, int mode)
 
 /* ---- packed int16 path (at_sweep16.hip.h): two same-shape pairs per wave ---- */
 struct Layout16 {
-	int off_refb, off_bound, off_ptr, g, k, ptr_lanes;
+	int off_refb, off_bound, off_ptr, off_sm, nsm, g, k, ptr_lanes;
 	long long words;
 };
 
@@ -278,10 +281,13 @@ static Layout16 layout16_for(bool tb, bool hasj, int l1, int l2)
 	nref = (nref + 1) & ~1LL;
 	const long long nbound = 2LL * (l2 + 2);
 	const long long nptr = tb ? nstrips * tbk * (blk / (hasj ? 2 : 4)) * L.k * L.ptr_lanes + 64 : 0;
+	const long long nsm = hasj ? (((long long)l2 + 64 + 64 + 128 + 31) / 32 + 2 + 1) & ~1LL : 0;
 	L.off_refb = (int)nref;
 	L.off_bound = (int)(2 * nref * ng);
-	L.off_ptr = (int)(2 * nref * ng + nbound);
-	L.words = 2 * nref * ng + nbound + nptr;
+	L.off_sm = (int)(2 * nref * ng + nbound);
+	L.nsm = (int)nsm;
+	L.off_ptr = (int)(2 * nref * ng + nbound + nsm);
+	L.words = 2 * nref * ng + nbound + nsm + nptr;
 	return L;
 }
 
@@ -451,7 +457,7 @@ extern "C" int at_align_batch_device(at_handle *h, int mode, int64_t npairs,
 		}
 		b.score = d_score; b.end_i = d_end_i; b.end_j = d_end_j; b.state = d_state;
 		b.ops = d_ops; b.ops_off = (const long long *)d_ops_off; b.nops = d_nops;
-		b.off_refb = P.off_refb; b.off_bound = P.off_bound; b.ptr_lanes = P.ptr_lanes;
+		b.off_refb = P.off_refb; b.off_bound = P.off_bound; b.ptr_lanes = P.ptr_lanes; b.off_sm = P.off_sm; b.nsm = P.nsm;
 		Plan pl;
 		const int per_wave = 2 * (64 / P.g);
 		char tag16[48];
@@ -479,7 +485,7 @@ extern "C" int at_align_batch_device(at_handle *h, int mode, int64_t npairs,
 	a.u_raw = h->u;
 	a.score = d_score; a.end_i = d_end_i; a.end_j = d_end_j; a.state = d_state;
 	a.ops = d_ops; a.ops_off = (const long long *)d_ops_off; a.nops = d_nops;
-	a.off_bound = L.off_bound; a.ptr_lanes = L.ptr_lanes;
+	a.off_bound = L.off_bound; a.ptr_lanes = L.ptr_lanes; a.off_sm = L.off_sm; a.nsm = L.nsm;
 	if (kmode == at::K_FITJ) {
 		int rc = ensure_sitemask(h, max_len2, stream);
 		if (rc) return rc;

@@ -75,6 +75,7 @@ struct SweepArgs {
 	uint32_t *ws;                  /* !SMALL: per-wave workspace slots             */
 	long long ws_slot_words;
 	int off_bound, off_ptr;        /* word offsets of the regions inside a slot    */
+	int off_sm, nsm;               /* fit -s: site mask words staged behind the boundary row */
 	int ptr_lanes;                 /* lanes per pointer row (min(64, ceil(max_l1/K))) */
 	unsigned long long *queue;     /* work counter, zeroed before every launch     */
 };
@@ -279,6 +280,9 @@ __global__ __launch_bounds__(64) void at_sweep(const SweepArgs a)
 				}
 			}
 		}
+		if constexpr (HASJ) {
+			for (int w = lane; w < a.nsm; w += 64) mem.st(a.off_sm + w, a.sitemask[w]);
+		}
 		/* ---- boundary row 0 ---- */
 		for (int j = lane; j <= l2; j += 64) {
 			if constexpr (AFFINE) {
@@ -387,7 +391,7 @@ __global__ __launch_bounds__(64) void at_sweep(const SweepArgs a)
 				uint32_t sm = 0;
 				if constexpr (HASJ) {
 					const int e0 = t0 - lane + 1 + 64;
-					const uint32_t w0 = a.sitemask[e0 >> 5], w1 = a.sitemask[(e0 >> 5) + 1];
+					const uint32_t w0 = mem.ld(a.off_sm + (e0 >> 5)), w1 = mem.ld(a.off_sm + (e0 >> 5) + 1);
 					sm = __builtin_amdgcn_alignbit(w1, w0, e0 & 31);
 				}
 				const int jm1_0 = t0 - lane;   /* 0-based column of step 0 of this block */

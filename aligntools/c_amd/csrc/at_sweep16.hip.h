@@ -50,7 +50,7 @@ struct Sweep16Args {
 	int *nops;
 	uint32_t *ws;
 	long long ws_slot_words;
-	int off_refb, off_bound, off_ptr;
+	int off_refb, off_bound, off_ptr, off_sm, nsm;   /* off_sm/nsm: site mask words staged behind the boundary row */
 	int ptr_lanes;
 	unsigned long long *queue;     /* work counter, zeroed before every launch */
 };
@@ -187,6 +187,9 @@ __global__ __launch_bounds__(64, AT_WAVES16(G, K)) void at_sweep16(const Sweep16
 				}
 			}
 		}
+		if constexpr (HASJ) {
+			for (int w = lane; w < a.nsm; w += 64) mem.st(a.off_sm + w, a.sitemask[w]);
+		}
 		/* ---- boundary row 0 (identical for every alignment of the batch) ---- */
 		for (int j = lane; j <= l2; j += 64) {
 			int L, M, U;
@@ -269,7 +272,7 @@ __global__ __launch_bounds__(64, AT_WAVES16(G, K)) void at_sweep16(const Sweep16
 				uint32_t sm = 0;
 				if constexpr (HASJ) {
 					const int e0 = t0 - lg + 1 + 64;
-					const uint32_t w0 = a.sitemask[e0 >> 5], w1 = a.sitemask[(e0 >> 5) + 1];
+					const uint32_t w0 = mem.ld(a.off_sm + (e0 >> 5)), w1 = mem.ld(a.off_sm + (e0 >> 5) + 1);
 					sm = __builtin_amdgcn_alignbit(w1, w0, e0 & 31);
 				}
 				const int jm1_0 = t0 - lg;

@@ -257,3 +257,24 @@ def test_packed16_score_range_extremes(al, mode):
                 assert int(res["score"][k]) == r["score"], (mode, l1, l2, sc, k)
                 assert (int(res["end_i"][k]), int(res["end_j"][k]), int(res["state"][k])) == (r["end_i"], r["end_j"], r["state"]), (mode, l1, l2, sc, k)
                 assert res["ops"][k] == r["ops"], (mode, l1, l2, sc, k)
+
+
+def test_score_only_batches(al):
+    """want_traceback = 0 (the TB = false kernels: no pointer matrix at all): scores, end cells and start
+    states still equal the oracle's, for the packed and the int32 kernels."""
+    rng = random.Random(9)
+    uniform = [("".join(rng.choice("ACGT") for _ in range(150)), "".join(rng.choice("ACGT") for _ in range(180))) for _ in range(37)]
+    ragged = [("".join(rng.choice("ACGT") for _ in range(rng.randint(1, 300))), "".join(rng.choice("ACGT") for _ in range(rng.randint(300, 400))))
+              for _ in range(21)]
+    for pairs, want in ((uniform, "packed16"), (ragged, "int32")):
+        for mode, uj in (("local", False), ("global", False), ("fit", False), ("fit", True), ("overlap", False), ("edit", False)):
+            al.set_scoring(2, -2, -5, -2, -6, uj, [100, 200])
+            res = al.align_batch(mode, pairs, traceback=False)
+            if mode in ("local", "global", "fit"):
+                assert want in al.last_config, (mode, al.last_config)
+            assert "ops" not in res
+            for k, (a, b) in enumerate(pairs):
+                r = O.align(O.MODE_NAMES[mode], a, b, 2, -2, -5, -2, -6, uj, [100, 200])
+                assert int(res["score"][k]) == r["score"], (mode, uj, k)
+                if mode != "edit":
+                    assert (int(res["end_i"][k]), int(res["end_j"][k]), int(res["state"][k])) == (r["end_i"], r["end_j"], r["state"])

@@ -24,7 +24,8 @@ ST_LOW, ST_MID, ST_UPP = 1, 2, 3
 
 # every symbol include/aligntools_hip.h declares
 ABI_SYMBOLS = ["at_init", "at_destroy", "at_last_error", "at_set_scoring", "at_align_batch",
-               "at_align_batch_device", "at_pack_words", "at_pack_batch", "at_render", "at_last_config"]
+               "at_align_batch_device", "at_align_allpairs_device", "at_pack_words", "at_pack_batch", "at_render",
+               "at_last_config"]
 
 _i32p = C.POINTER(C.c_int32)
 _i64p = C.POINTER(C.c_int64)
@@ -67,6 +68,10 @@ def load_library():
                                           C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int, C.c_int,
                                           C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                           C.c_void_p, C.c_void_p]
+    lib.at_align_allpairs_device.restype = C.c_int
+    lib.at_align_allpairs_device.argtypes = [C.c_void_p, C.c_int, C.c_int64, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p,
+                                             C.c_int32, C.c_int64, C.c_int64, C.c_int, C.c_void_p, C.c_void_p,
+                                             C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
     lib.at_pack_words.restype = C.c_int64
     lib.at_pack_words.argtypes = [C.c_int64, C.c_void_p, C.c_void_p, C.c_int]
     lib.at_pack_batch.restype = C.c_int
@@ -219,6 +224,14 @@ class Aligner:
                                                     max_len1, max_len2, 1 if uniform_shape else 0,
                                                     1 if want_traceback else 0, d_score, d_end_i,
                                                     d_end_j, d_state, d_ops, d_ops_off, d_nops, stream))
+
+
+    def align_allpairs_device(self, mode, nreads, d_seq, bits, d_woff, d_len, max_len, first_pair, npairs, want_traceback,
+                              d_score, d_end_i, d_end_j, d_state, d_ops, d_ops_off, d_nops, stream=0):
+        """All ordered pairs (a < b) of one read set; see at_align_allpairs_device in include/aligntools_hip.h."""
+        self._check(self._lib.at_align_allpairs_device(self._h, mode, nreads, d_seq, bits, d_woff, d_len, max_len, first_pair,
+                                                       npairs, 1 if want_traceback else 0, d_score, d_end_i, d_end_j, d_state,
+                                                       d_ops, d_ops_off, d_nops, stream))
 
 
 _default = None

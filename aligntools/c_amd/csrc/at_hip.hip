@@ -407,6 +407,15 @@ static int plan_launch(at_handle *h, const char *tag, int k, long long nwork, lo
 	return AT_OK;
 }
 
+static int align_device(at_handle *h, int mode, int64_t npairs,
+                        const uint32_t *d_seq, int bits,
+                        const int64_t *d_woff1, const int32_t *d_len1,
+                        const int64_t *d_woff2, const int32_t *d_len2,
+                        int32_t max_len1, int32_t max_len2, int uniform_shape, int want_traceback,
+                        int32_t *d_score, int32_t *d_end_i, int32_t *d_end_j, int32_t *d_state,
+                        uint8_t *d_ops, const int64_t *d_ops_off, int32_t *d_nops, void *stream_,
+                        int64_t ap_n, int64_t ap_first);
+
 extern "C" int at_align_batch_device(at_handle *h, int mode, int64_t npairs,
                                      const uint32_t *d_seq, int bits,
                                      const int64_t *d_woff1, const int32_t *d_len1,
@@ -414,6 +423,35 @@ extern "C" int at_align_batch_device(at_handle *h, int mode, int64_t npairs,
                                      int32_t max_len1, int32_t max_len2, int uniform_shape, int want_traceback,
                                      int32_t *d_score, int32_t *d_end_i, int32_t *d_end_j, int32_t *d_state,
                                      uint8_t *d_ops, const int64_t *d_ops_off, int32_t *d_nops, void *stream_)
+{
+	if (!d_woff2 || !d_len2) return fail(h, AT_ERR_ARG, "NULL device pointer");
+	return align_device(h, mode, npairs, d_seq, bits, d_woff1, d_len1, d_woff2, d_len2, max_len1, max_len2, uniform_shape,
+	                    want_traceback, d_score, d_end_i, d_end_j, d_state, d_ops, d_ops_off, d_nops, stream_, 0, 0);
+}
+
+extern "C" int at_align_allpairs_device(at_handle *h, int mode, int64_t nreads,
+                                        const uint32_t *d_seq, int bits,
+                                        const int64_t *d_woff, const int32_t *d_len, int32_t max_len,
+                                        int64_t first_pair, int64_t npairs, int want_traceback,
+                                        int32_t *d_score, int32_t *d_end_i, int32_t *d_end_j, int32_t *d_state,
+                                        uint8_t *d_ops, const int64_t *d_ops_off, int32_t *d_nops, void *stream_)
+{
+	if (!h) return fail(nullptr, AT_ERR_ARG, "at_align_allpairs_device: NULL handle");
+	if (nreads < 2 || first_pair < 0 || npairs < 0 || first_pair + npairs > nreads * (nreads - 1) / 2)
+		return fail(h, AT_ERR_ARG, "all-vs-all: pair range [%lld, +%lld) outside the %lld*(%lld-1)/2 ordered pairs",
+		            (long long)first_pair, (long long)npairs, (long long)nreads, (long long)nreads);
+	return align_device(h, mode, npairs, d_seq, bits, d_woff, d_len, d_woff, d_len, max_len, max_len, 0, want_traceback,
+	                    d_score, d_end_i, d_end_j, d_state, d_ops, d_ops_off, d_nops, stream_, nreads, first_pair);
+}
+
+static int align_device(at_handle *h, int mode, int64_t npairs,
+                        const uint32_t *d_seq, int bits,
+                        const int64_t *d_woff1, const int32_t *d_len1,
+                        const int64_t *d_woff2, const int32_t *d_len2,
+                        int32_t max_len1, int32_t max_len2, int uniform_shape, int want_traceback,
+                        int32_t *d_score, int32_t *d_end_i, int32_t *d_end_j, int32_t *d_state,
+                        uint8_t *d_ops, const int64_t *d_ops_off, int32_t *d_nops, void *stream_,
+                        int64_t ap_n, int64_t ap_first)
 {
 	if (!h) return fail(nullptr, AT_ERR_ARG, "at_align_batch_device: NULL handle");
 	if (mode < AT_MODE_GLOBAL || mode > AT_MODE_EDIT) return fail(h, AT_ERR_ARG, "unknown mode %d", mode);
@@ -442,7 +480,7 @@ extern "C" int at_align_batch_device(at_handle *h, int mode, int64_t npairs,
 
 	/* ---- packed int16 path: uniform shape, scores provably within 16 bits ---- */
 	int thresh16 = 0;
-	if (uniform_shape && packed_ok(h, mode, bits, max_len1, max_len2, &thresh16)) {
+	if (uniform_shape && ap_n == 0 && packed_ok(h, mode, bits, max_len1, max_len2, &thresh16)) {
 		const Layout16 P = layout16_for(tb, kmode == at::K_FITJ, max_len1, max_len2);
 		Sweep16Args b;
 		memset(&b, 0, sizeof b);
@@ -486,6 +524,7 @@ extern "C" int at_align_batch_device(at_handle *h, int mode, int64_t npairs,
 	a.score = d_score; a.end_i = d_end_i; a.end_j = d_end_j; a.state = d_state;
 	a.ops = d_ops; a.ops_off = (const long long *)d_ops_off; a.nops = d_nops;
 	a.off_bound = L.off_bound; a.ptr_lanes = L.ptr_lanes; a.off_sm = L.off_sm; a.nsm = L.nsm;
+	a.ap_n = ap_n; a.ap_first = ap_first;
 	if (kmode == at::K_FITJ) {
 		int rc = ensure_sitemask(h, max_len2, stream);
 		if (rc) return rc;

@@ -78,11 +78,28 @@ struct SweepArgs {
 	int off_sm, nsm;               /* fit -s: site mask words staged behind the boundary row */
 	int ptr_lanes;                 /* lanes per pointer row (min(64, ceil(max_l1/K))) */
 	unsigned long long *queue;     /* work counter, zeroed before every launch     */
+	/* all-vs-all mode (ap_n > 0): woff1/len1 describe ap_n READS; work item p is the ordered pair (a < b)
+	 * with linear triangle index ap_first + p; woff2/len2 are unused */
+	long long ap_n, ap_first;
 };
 
 extern __shared__ uint32_t at_lds[];
 
 #define AT_DEV __device__ __forceinline__
+
+/* linear index t of the strict upper triangle of an n x n matrix (row-major) -> (a, b), a < b */
+AT_DEV void tri_pair(long long t, long long n, long long &ia, long long &ib)
+{
+	const double d = (double)(2 * n - 1);
+	long long r = (long long)((d - sqrt(d * d - 8.0 * (double)t)) * 0.5);
+	if (r < 0) r = 0;
+	if (r > n - 2) r = n - 2;
+	/* pairs before row r: r*(2n - r - 1)/2; correct the floating-point guess */
+	while (r > 0 && r * (2 * n - r - 1) / 2 > t) --r;
+	while ((r + 1) * (2 * n - r - 2) / 2 <= t) ++r;
+	ia = r;
+	ib = t - r * (2 * n - r - 1) / 2 + r + 1;
+}
 
 /* __shfl_up(x, 1) as one DPP move; lane 0 (no source lane) keeps `old`. */
 AT_DEV int shfl_up1(int old, int src)
@@ -255,10 +272,12 @@ __global__ __launch_bounds__(64) void at_sweep(const SweepArgs a)
 	while (pnext < a.npairs) {
 		const long long p = pnext;
 		pnext = next_work(a.queue, lane);   /* consumed at the end of this pair: latency hidden */
-		const int l1 = uni(a.len1[p]);
-		const int l2 = uni(a.len2[p]);
-		const uint32_t *q_words = a.seq + a.woff1[p];
-		const uint32_t *r_words = a.seq + a.woff2[p];
+		long long ia = p, ib = p;
+		if (a.ap_n > 0) tri_pair(a.ap_first + p, a.ap_n, ia, ib);
+		const int l1 = uni(a.len1[ia]);
+		const int l2 = uni(a.ap_n > 0 ? a.len1[ib] : a.len2[ib]);
+		const uint32_t *q_words = a.seq + a.woff1[ia];
+		const uint32_t *r_words = a.seq + (a.ap_n > 0 ? a.woff1[ib] : a.woff2[ib]);
 		const int nstrips = (l1 + RS - 1) / RS;
 		const int tbk = (l2 + 63 + kBlk - 1) / kBlk;   /* blocks per strip           */
 		const int wps = tbk * RPB * K;                 /* pointer word rows per strip */

@@ -115,6 +115,21 @@ int at_align_batch_device(at_handle *h, int mode, int64_t npairs,
                           uint8_t *d_ops, const int64_t *d_ops_off, int32_t *d_nops,
                           void *stream);
 
+/*
+ * All-vs-all over one read set (BASELINE config "overlap, all-vs-all 50k x 1 kbp reads"): d_woff/d_len
+ * describe `nreads` packed reads; work item p in [0, npairs) is the ordered pair (a < b) whose row-major
+ * index in the strict upper triangle is first_pair + p, aligned as s1 = read a, s2 = read b.  No per-pair
+ * descriptors exist (1.25e9 pairs would need 30 GB of them); outputs are indexed by p.  Ranks of a
+ * multi-GPU job take disjoint [first_pair, first_pair + npairs) ranges.
+ */
+int at_align_allpairs_device(at_handle *h, int mode, int64_t nreads,
+                             const uint32_t *d_seq, int bits,
+                             const int64_t *d_woff, const int32_t *d_len, int32_t max_len,
+                             int64_t first_pair, int64_t npairs, int want_traceback,
+                             int32_t *d_score, int32_t *d_end_i, int32_t *d_end_j, int32_t *d_state,
+                             uint8_t *d_ops, const int64_t *d_ops_off, int32_t *d_nops,
+                             void *stream);
+
 /* Host helper: pack `npairs` pairs of raw bytes into the word layout above.
  * bits = 0 picks 2 when every byte is one of ACGT, else 8; the choice is
  * returned in *bits_out.  words_out must hold at_pack_words(...) int32s. */

@@ -278,3 +278,46 @@ def test_score_only_batches(al):
                 assert int(res["score"][k]) == r["score"], (mode, uj, k)
                 if mode != "edit":
                     assert (int(res["end_i"][k]), int(res["end_j"][k]), int(res["state"][k])) == (r["end_i"], r["end_j"], r["state"])
+
+
+def test_all_vs_all_mode(al):
+    """BASELINE config 'overlap all-vs-all': ordered pairs (a < b) enumerated on the GPU from a linear triangle
+    index (no per-pair descriptors), split in two ranges like two ranks would; every pair equals the oracle."""
+    import numpy as np
+    import torch
+    import aligntools.c_amd as A
+    rng = random.Random(31)
+    reads = []
+    base = "".join(rng.choice("ACGT") for _ in range(400))
+    for k in range(41):
+        st = rng.randint(0, 200)
+        reads.append(base[st:st + rng.randint(80, 200)] + "".join(rng.choice("ACGT") for _ in range(rng.randint(0, 30))))
+    n = len(reads)
+    words, woff, _w2, lens, _l2, bits = A.pack_pairs([(r.encode(), b"") for r in reads])
+    dev = torch.device("cuda", 0)
+    d_words = torch.from_numpy(words.view(np.int32)).to(dev)
+    d_woff = torch.from_numpy(woff).to(dev)
+    d_len = torch.from_numpy(lens).to(dev)
+    total = n * (n - 1) // 2
+    maxl = int(lens.max())
+    for mode in ("overlap", "local"):
+        al.set_scoring(1, -2, -5, -1)
+        got = {}
+        for first, cnt in ((0, 300), (300, total - 300)):
+            res = torch.zeros((5, cnt), dtype=torch.int32, device=dev)
+            ops = torch.zeros(cnt * 2 * maxl + 64, dtype=torch.uint8, device=dev)
+            ops_off = torch.arange(cnt, dtype=torch.int64, device=dev) * (2 * maxl)
+            al.align_allpairs_device(A.MODES[mode], n, d_words.data_ptr(), bits, d_woff.data_ptr(), d_len.data_ptr(), maxl,
+                                     first, cnt, True, res[0].data_ptr(), res[1].data_ptr(), res[2].data_ptr(), res[3].data_ptr(),
+                                     ops.data_ptr(), ops_off.data_ptr(), res[4].data_ptr(), torch.cuda.current_stream().cuda_stream)
+            torch.cuda.synchronize()
+            r, o = res.cpu().numpy(), ops.cpu().numpy()
+            for p in range(cnt):
+                got[first + p] = (int(r[0, p]), int(r[1, p]), int(r[2, p]), bytes(o[p * 2 * maxl: p * 2 * maxl + int(r[4, p])]))
+        t = 0
+        for a in range(n):
+            for b in range(a + 1, n):
+                ref = O.align(O.MODE_NAMES[mode], reads[a], reads[b], 1, -2, -5, -1)
+                assert got[t] == (ref["score"], ref["end_i"], ref["end_j"], ref["ops"]), (mode, a, b)
+                t += 1
+        assert t == total

@@ -40,6 +40,9 @@ WORKLOADS = {
     "C3": ("global", 1024, 1024, 10000, (1, -1, -4, -1, -10), False, [], 0x5EED0003),
     "C4": ("fit", 150, 500, 100000, (2, -2, -5, -1, -10), True, [100, 200, 300, 400], 0x5EED0004),
     "C5": ("overlap", 1000, 1000, 10000, (1, -2, -5, -1, -10), False, [], 0x5EED0005),
+    # all-vs-all over 50k reads of 1 kbp (1.25e9 ordered pairs in full): each step scores a 100k-pair slice of the
+    # triangle per GPU, pairs enumerated on the GPU (at_align_allpairs_device), scores + end cells only
+    "C5all": ("overlap", 1000, 1000, 100000, (1, -2, -5, -1, -10), False, [], 0x5EED0005),
 }
 
 
@@ -111,10 +114,16 @@ def main():
     al.set_scoring(m, u, o, e, j, bool(uj), scl[7:7 + ns])
 
     # ---- this rank's shard of the synthetic batch, packed, resident in HBM ----
-    blob = synth_pairs_blob(seed, pairs, l1, l2, first_pair=rank * pairs)
-    plist = [(row[:l1].tobytes(), row[l1:].tobytes()) for row in blob]
+    allpairs = args.workload == "C5all"
+    if allpairs:
+        nreads = 50000
+        blob = synth_pairs_blob(seed, nreads // 2, l1, l2)           # 25k rows of two 1 kbp reads
+        plist = [(row[k * l1:(k + 1) * l1].tobytes(), b"") for row in blob for k in range(2)]
+    else:
+        blob = synth_pairs_blob(seed, pairs, l1, l2, first_pair=rank * pairs)
+        plist = [(row[:l1].tobytes(), row[l1:].tobytes()) for row in blob]
     words, woff1, woff2, len1, len2, bits = A.pack_pairs(plist)
-    tb = (not args.no_traceback) and mode != "edit"
+    tb = (not args.no_traceback) and mode != "edit" and not allpairs
     d_words = torch.from_numpy(words.view(np.int32)).to(dev)
     d_woff1 = torch.from_numpy(woff1).to(dev)
     d_woff2 = torch.from_numpy(woff2).to(dev)
@@ -131,11 +140,17 @@ def main():
     def step(k):
         d_res = d_res2[k & 1]
         stream = torch.cuda.current_stream().cuda_stream
-        al.align_batch_device(A.MODES[mode], pairs, d_words.data_ptr(), bits, d_woff1.data_ptr(), d_len1.data_ptr(),
-                              d_woff2.data_ptr(), d_len2.data_ptr(), l1, l2, True, tb,
-                              d_res[0].data_ptr(), d_res[1].data_ptr(), d_res[2].data_ptr(), d_res[3].data_ptr(),
-                              d_ops.data_ptr() if tb else None, d_ops_off.data_ptr() if tb else None,
-                              d_nops.data_ptr() if tb else None, stream)
+        if allpairs:   # this rank's slice of the triangle, a different one every step
+            first = ((k * world + rank) * pairs) % (nreads * (nreads - 1) // 2 - pairs)
+            al.align_allpairs_device(A.MODES[mode], nreads, d_words.data_ptr(), bits, d_woff1.data_ptr(), d_len1.data_ptr(), l1,
+                                     first, pairs, False, d_res[0].data_ptr(), d_res[1].data_ptr(), d_res[2].data_ptr(),
+                                     d_res[3].data_ptr(), None, None, None, stream)
+        else:
+            al.align_batch_device(A.MODES[mode], pairs, d_words.data_ptr(), bits, d_woff1.data_ptr(), d_len1.data_ptr(),
+                                  d_woff2.data_ptr(), d_len2.data_ptr(), l1, l2, True, tb,
+                                  d_res[0].data_ptr(), d_res[1].data_ptr(), d_res[2].data_ptr(), d_res[3].data_ptr(),
+                                  d_ops.data_ptr() if tb else None, d_ops_off.data_ptr() if tb else None,
+                                  d_nops.data_ptr() if tb else None, stream)
         if use_dist:   # gather the fixed-size results of this step; overlaps the next step's kernel
             return dist.all_gather_into_tensor(gathered[k & 1], d_res, async_op=True)
         return None

@@ -260,7 +260,7 @@ struct Layout16 {
 	long long words;
 };
 
-/* Group width: reads of 97..208 bases run as 4 groups of 16 lanes x K rows (8 alignments per wave, 85 % of the
+/* Group width: reads of 49..208 bases run as 4 groups of 16 lanes x K rows (8 alignments per wave, 85 % of the
  * lane-steps inside a 150 x 150 matrix instead of 59 %); everything else as one group of 64 lanes. */
 static Layout16 layout16_for(bool tb, bool hasj, int l1, int l2)
 {
@@ -268,9 +268,9 @@ static Layout16 layout16_for(bool tb, bool hasj, int l1, int l2)
 	const long long g_forced = env_ll("AT_GROUP", 0);
 	L.g = 64;
 	L.k = rows_per_lane(l1);
-	if (g_forced != 64 && l1 > 96 && l1 <= 208) {
+	if (g_forced != 64 && l1 > 48 && l1 <= 208) {
 		L.g = 16;
-		L.k = l1 <= 112 ? 7 : (l1 <= 160 ? 10 : 13);
+		L.k = l1 <= 64 ? 4 : l1 <= 80 ? 5 : l1 <= 96 ? 6 : l1 <= 112 ? 7 : (l1 <= 160 ? 10 : 13);
 	}
 	const int ng = 64 / L.g;
 	const int blk = L.g == 16 ? 4 : 8;        /* BLK of at_sweep16 */
@@ -504,6 +504,7 @@ static int align_device(at_handle *h, int mode, int64_t npairs,
 		if (rc) return rc;
 		b.off_ptr = pl.off_ptr; b.ws = pl.ws; b.ws_slot_words = pl.slot_words; b.queue = h->d_queue;
 		at_sweep16_fn fn16 = at_pick16(kmode, P.g, P.k, pl.store, tb);
+		if (!fn16 || (P.g == 16 && pl.store == 2)) return fail(h, AT_ERR_RANGE, "no packed kernel for this shape (rows/lane=%d, store=%d)", P.k, pl.store);
 		if (pl.dyn_lds > 48 * 1024)
 			HIP_TRY(h, hipFuncSetAttribute((const void *)fn16, hipFuncAttributeMaxDynamicSharedMemorySize, (int)pl.dyn_lds));
 		hipLaunchKernelGGL(fn16, dim3((unsigned)pl.grid), dim3(64), pl.dyn_lds, stream, b);

@@ -1,0 +1,7 @@
+#include "at_launch.h"
+at_sweep16_fn at_pick16_g16a(int kmode, int k, int store, bool tb);
+at_sweep16_fn at_pick16_g16b(int kmode, int k, int store, bool tb);
+at_sweep16_fn at_pick16_g16(int kmode, int k, int store, bool tb)
+{
+	return k >= 10 ? at_pick16_g16b(kmode, k, store, tb) : at_pick16_g16a(kmode, k, store, tb);
+}

@@ -34,6 +34,7 @@ struct at_handle {
 	void *d_in = nullptr; size_t in_bytes = 0;
 	void *d_out = nullptr; size_t out_bytes = 0;
 	void *d_desc = nullptr; size_t desc_bytes = 0;
+	void *d_order = nullptr; size_t order_bytes = 0;
 	char err[512] = {0};
 	char cfg[160] = "none";
 };
@@ -100,6 +101,7 @@ extern "C" void at_destroy(at_handle *h)
 	if (h->d_in) (void)hipFree(h->d_in);
 	if (h->d_out) (void)hipFree(h->d_out);
 	if (h->d_desc) (void)hipFree(h->d_desc);
+	if (h->d_order) (void)hipFree(h->d_order);
 	if (h->stream) (void)hipStreamDestroy(h->stream);
 	delete h;
 }
@@ -414,7 +416,7 @@ static int align_device(at_handle *h, int mode, int64_t npairs,
                         int32_t max_len1, int32_t max_len2, int uniform_shape, int want_traceback,
                         int32_t *d_score, int32_t *d_end_i, int32_t *d_end_j, int32_t *d_state,
                         uint8_t *d_ops, const int64_t *d_ops_off, int32_t *d_nops, void *stream_,
-                        int64_t ap_n, int64_t ap_first);
+                        int64_t ap_n, int64_t ap_first, const int *d_order = nullptr);
 
 extern "C" int at_align_batch_device(at_handle *h, int mode, int64_t npairs,
                                      const uint32_t *d_seq, int bits,
@@ -451,7 +453,7 @@ static int align_device(at_handle *h, int mode, int64_t npairs,
                         int32_t max_len1, int32_t max_len2, int uniform_shape, int want_traceback,
                         int32_t *d_score, int32_t *d_end_i, int32_t *d_end_j, int32_t *d_state,
                         uint8_t *d_ops, const int64_t *d_ops_off, int32_t *d_nops, void *stream_,
-                        int64_t ap_n, int64_t ap_first)
+                        int64_t ap_n, int64_t ap_first, const int *d_order)
 {
 	if (!h) return fail(nullptr, AT_ERR_ARG, "at_align_batch_device: NULL handle");
 	if (mode < AT_MODE_GLOBAL || mode > AT_MODE_EDIT) return fail(h, AT_ERR_ARG, "unknown mode %d", mode);
@@ -525,7 +527,7 @@ static int align_device(at_handle *h, int mode, int64_t npairs,
 	a.score = d_score; a.end_i = d_end_i; a.end_j = d_end_j; a.state = d_state;
 	a.ops = d_ops; a.ops_off = (const long long *)d_ops_off; a.nops = d_nops;
 	a.off_bound = L.off_bound; a.ptr_lanes = L.ptr_lanes; a.off_sm = L.off_sm; a.nsm = L.nsm;
-	a.ap_n = ap_n; a.ap_first = ap_first;
+	a.ap_n = ap_n; a.ap_first = ap_first; a.order = d_order;
 	if (kmode == at::K_FITJ) {
 		int rc = ensure_sitemask(h, max_len2, stream);
 		if (rc) return rc;
@@ -658,8 +660,23 @@ extern "C" int at_align_batch(at_handle *h, int mode, int64_t npairs, const uint
 	int32_t *d_st = (int32_t *)(dout + 3 * b_len1), *d_nops = (int32_t *)(dout + 4 * b_len1);
 	uint8_t *d_ops = (uint8_t *)(dout + 5 * b_len1);
 
-	rc = at_align_batch_device(h, mode, npairs, d_words, bits, d_woff1, d_len1, d_woff2, d_len2, max1, max2, uniform ? 1 : 0, tb ? 1 : 0,
-	                           d_score, d_ei, d_ej, d_st, tb ? d_ops : nullptr, tb ? d_opsoff : nullptr, tb ? d_nops : nullptr, s);
+	/* ragged batch: hand the pairs out largest first (the work queue is dynamic, so a big pair picked up last
+	 * would otherwise run alone at the end) */
+	int *d_order = nullptr;
+	if (!uniform && npairs > 1 && npairs < (1LL << 31)) {
+		std::vector<int> order((size_t)npairs);
+		for (int64_t k = 0; k < npairs; ++k) order[(size_t)k] = (int)k;
+		std::stable_sort(order.begin(), order.end(), [&](int x, int y) {
+			return (int64_t)len1[x] * len2[x] > (int64_t)len1[y] * len2[y];
+		});
+		rc = grow(h, &h->d_order, &h->order_bytes, (size_t)npairs * 4);
+		if (rc) return rc;
+		d_order = (int *)h->d_order;
+		HIP_TRY(h, hipMemcpyAsync(d_order, order.data(), (size_t)npairs * 4, hipMemcpyHostToDevice, s));
+		HIP_TRY(h, hipStreamSynchronize(s));
+	}
+	rc = align_device(h, mode, npairs, d_words, bits, d_woff1, d_len1, d_woff2, d_len2, max1, max2, uniform ? 1 : 0, tb ? 1 : 0,
+	                  d_score, d_ei, d_ej, d_st, tb ? d_ops : nullptr, tb ? d_opsoff : nullptr, tb ? d_nops : nullptr, s, 0, 0, d_order);
 	if (rc) return rc;
 	HIP_TRY(h, hipMemcpyAsync(out_score, d_score, (size_t)npairs * 4, hipMemcpyDeviceToHost, s));
 	if (out_end_i) HIP_TRY(h, hipMemcpyAsync(out_end_i, d_ei, (size_t)npairs * 4, hipMemcpyDeviceToHost, s));

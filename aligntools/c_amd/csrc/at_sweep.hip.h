@@ -81,6 +81,8 @@ struct SweepArgs {
 	/* all-vs-all mode (ap_n > 0): woff1/len1 describe ap_n READS; work item p is the ordered pair (a < b)
 	 * with linear triangle index ap_first + p; woff2/len2 are unused */
 	long long ap_n, ap_first;
+	/* optional processing order (largest pairs first, so that ragged batches end without a long straggler) */
+	const int *order;
 };
 
 extern __shared__ uint32_t at_lds[];
@@ -270,7 +272,7 @@ __global__ __launch_bounds__(64) void at_sweep(const SweepArgs a)
 
 	long long pnext = next_work(a.queue, lane);
 	while (pnext < a.npairs) {
-		const long long p = pnext;
+		const long long p = a.order ? (long long)a.order[pnext] : pnext;
 		pnext = next_work(a.queue, lane);   /* consumed at the end of this pair: latency hidden */
 		long long ia = p, ib = p;
 		if (a.ap_n > 0) tri_pair(a.ap_first + p, a.ap_n, ia, ib);

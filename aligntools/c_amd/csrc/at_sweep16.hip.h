@@ -164,7 +164,7 @@ __global__ __launch_bounds__(64, AT_WAVES16(G, K)) void at_sweep16(const Sweep16
 	const long long nwork = (a.npairs + 2 * NG - 1) / (2 * NG);
 	const int refoff = grp * 2 * a.off_refb;  /* my group's two s2 byte arrays */
 
-	long long wnext = next_work(a.queue, lane);
+	long long wnext = blockIdx.x;
 	while (wnext < nwork) {
 		const long long wk = wnext;
 		wnext = next_work(a.queue, lane);   /* consumed at the end of this work item: latency hidden */

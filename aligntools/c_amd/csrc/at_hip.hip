@@ -264,13 +264,13 @@ struct Layout16 {
 
 /* Group width: reads of 49..208 bases run as 4 groups of 16 lanes x K rows (8 alignments per wave, 85 % of the
  * lane-steps inside a 150 x 150 matrix instead of 59 %); everything else as one group of 64 lanes. */
-static Layout16 layout16_for(bool tb, bool hasj, int l1, int l2)
+static Layout16 layout16_for(bool tb, bool hasj, int l1, int l2, int ts)
 {
 	Layout16 L;
 	const long long g_forced = env_ll("AT_GROUP", 0);
 	L.g = 64;
 	L.k = rows_per_lane(l1);
-	if (g_forced != 64 && l1 > 48 && l1 <= 208) {
+	if (g_forced != 64 && ts == 4 && l1 > 48 && l1 <= 208) {
 		L.g = 16;
 		L.k = l1 <= 64 ? 4 : l1 <= 80 ? 5 : l1 <= 96 ? 6 : l1 <= 112 ? 7 : (l1 <= 160 ? 10 : 13);
 	}
@@ -296,20 +296,21 @@ static Layout16 layout16_for(bool tb, bool hasj, int l1, int l2)
 /* Scores of every real (non -inf) cell lie in [-lo, hi]; the packed kernel needs
  * 16*(lo + hi) plus slack below 2^15 so that the -32768 sentinel, even after the
  * hi*16 it can gain along a diagonal of matches, stays below every real value. */
-static bool packed_ok(const at_handle *h, int mode, int bits, int l1, int l2, int *thresh16)
+static bool packed_ok(const at_handle *h, int mode, int bits, int l1, int l2, int ts, int *thresh16)
 {
+	const long long scale = 1LL << ts;
 	if (getenv("AT_NO_PACKED") && atoi(getenv("AT_NO_PACKED"))) return false;
 	if (bits != 2 || l1 < 1 || l2 < 1) return false;
 	if (!(mode == AT_MODE_GLOBAL || mode == AT_MODE_LOCAL || mode == AT_MODE_FIT)) return false;
 	if (h->m < 0 || h->u > 0 || h->o > 0 || h->e > 0) return false;
 	const bool hasj = mode == AT_MODE_FIT && h->use_jump;
-	if (hasj && (h->j > 0 || std::llabs((long long)h->j - h->o) * 16 > 32000)) return false;
+	if (hasj && (h->j > 0 || std::llabs((long long)h->j - h->o) * scale > 32000)) return false;
 	const long long A = std::max<long long>(std::max(std::llabs((long long)h->e), std::llabs((long long)h->u)), h->m);
 	const long long lo = 3 * std::llabs((long long)h->o) + (hasj ? std::llabs((long long)h->j) : 0) + A * ((long long)l1 + l2) + 16;
 	const long long hi = (long long)h->m * std::min(l1, l2);
 	const long long slack = std::llabs((long long)h->o) + std::llabs((long long)h->e) + 3;
-	if (16 * (lo + hi + slack) >= 32768) return false;
-	*thresh16 = (int)(-32768 + 16 * (hi + slack));
+	if (scale * (lo + hi + slack) >= 32768) return false;
+	*thresh16 = (int)(-32768 + scale * (hi + slack));
 	return true;
 }
 
@@ -481,15 +482,29 @@ static int align_device(at_handle *h, int mode, int64_t npairs,
 	                : mode == AT_MODE_OVERLAP ? at::K_OVERLAP : at::K_EDIT;
 
 	/* ---- packed int16 path: uniform shape, scores provably within 16 bits ---- */
-	int thresh16 = 0;
-	if (uniform_shape && ap_n == 0 && packed_ok(h, mode, bits, max_len1, max_len2, &thresh16)) {
-		const Layout16 P = layout16_for(tb, kmode == at::K_FITJ, max_len1, max_len2);
+	/* scores x16 with nibble pointers when they fit (|score| < 2048), else x4 with byte pointers (|score| < 8192) */
+	int thresh16 = 0, ts = 0;
+	if (uniform_shape && ap_n == 0) {
+		if (packed_ok(h, mode, bits, max_len1, max_len2, 4, &thresh16)) ts = 4;
+		else if (packed_ok(h, mode, bits, max_len1, max_len2, 2, &thresh16)) ts = 2;
+	}
+	Layout16 P;
+	if (ts) {
+		P = layout16_for(tb, kmode == at::K_FITJ, max_len1, max_len2, ts);
+		/* A 64-lane packed wave carries 2 alignments where an int32 wave carries 1: fewer, longer work items.  With
+		 * only a round or two of them the coarser granularity costs more than the packing saves (measured on
+		 * 10k x 1024^2: 1.92 vs 2.03 TCUPS; at 61k pairs 2.70 vs 2.19), so small batches stay on the int32 kernel. */
+		const double min_rounds = getenv("AT_PACKED_MIN_ROUNDS") ? atof(getenv("AT_PACKED_MIN_ROUNDS")) : 2.5;
+		if (P.g == 64 && (double)((npairs + 1) / 2) < min_rounds * 12.0 * h->ncu) ts = 0;
+	}
+	if (ts) {
 		Sweep16Args b;
 		memset(&b, 0, sizeof b);
 		b.npairs = npairs; b.seq = d_seq;
 		b.woff1 = (const long long *)d_woff1; b.woff2 = (const long long *)d_woff2;
 		b.l1 = max_len1; b.l2 = max_len2;
-		b.m16 = h->m * 16; b.u16 = h->u * 16; b.o16 = h->o * 16; b.e16 = h->e * 16; b.g16 = h->j * 16; b.thresh16 = thresh16;
+		const int sc = 1 << ts;
+		b.m16 = h->m * sc; b.u16 = h->u * sc; b.o16 = h->o * sc; b.e16 = h->e * sc; b.g16 = h->j * sc; b.thresh16 = thresh16;
 		if (kmode == at::K_FITJ) {
 			int rcs = ensure_sitemask(h, max_len2, stream);
 			if (rcs) return rcs;
@@ -501,11 +516,11 @@ static int align_device(at_handle *h, int mode, int64_t npairs,
 		Plan pl;
 		const int per_wave = 2 * (64 / P.g);
 		char tag16[64];
-		snprintf(tag16, sizeof tag16, "packed16 %dx%d-lane groups (%d pairs/wave)", 64 / P.g, P.g, per_wave);
+		snprintf(tag16, sizeof tag16, "packed16 x%d %dx%d-lane groups (%d pairs/wave)", 1 << ts, 64 / P.g, P.g, per_wave);
 		int rc = plan_launch(h, tag16, P.k, (npairs + per_wave - 1) / per_wave, P.off_ptr, P.words - P.off_ptr, &pl, stream);
 		if (rc) return rc;
 		b.off_ptr = pl.off_ptr; b.ws = pl.ws; b.ws_slot_words = pl.slot_words; b.queue = h->d_queue;
-		at_sweep16_fn fn16 = at_pick16(kmode, P.g, P.k, pl.store, tb);
+		at_sweep16_fn fn16 = at_pick16(kmode, P.g, P.k, ts, pl.store, tb);
 		if (!fn16 || (P.g == 16 && pl.store == 2)) return fail(h, AT_ERR_RANGE, "no packed kernel for this shape (rows/lane=%d, store=%d)", P.k, pl.store);
 		if (pl.dyn_lds > 48 * 1024)
 			HIP_TRY(h, hipFuncSetAttribute((const void *)fn16, hipFuncAttributeMaxDynamicSharedMemorySize, (int)pl.dyn_lds));

@@ -1,31 +1,9 @@
 #include "at_launch.h"
-/* packed kernels, one group of 64 lanes: K in 1..4 rows per lane (reads up to 48 bases, and 209+ with strips) */
-template <int MODE, int K>
-static at_sweep16_fn p3(int store, bool tb)
-{
-	if (!tb) return store < 2 ? at::at_sweep16<MODE, 64, K, true, true, false> : at::at_sweep16<MODE, 64, K, false, false, false>;
-	if (store == 0) return at::at_sweep16<MODE, 64, K, true, true, true>;
-	if (store == 1) return at::at_sweep16<MODE, 64, K, true, false, true>;
-	return at::at_sweep16<MODE, 64, K, false, false, true>;
-}
-template <int MODE>
-static at_sweep16_fn p2(int k, int store, bool tb)
-{
-	switch (k) {
-	case 1: return p3<MODE, 1>(store, tb);
-	case 2: return p3<MODE, 2>(store, tb);
-	case 3: return p3<MODE, 3>(store, tb);
-	default: return p3<MODE, 4>(store, tb);
-	}
-}
+at_sweep16_fn at_pick16_g64_ts4(int kmode, int k, int store, bool tb);
+at_sweep16_fn at_pick16_g64_ts2(int kmode, int k, int store, bool tb);
 at_sweep16_fn at_pick16_g16(int kmode, int k, int store, bool tb);
-at_sweep16_fn at_pick16(int kmode, int g, int k, int store, bool tb)
+at_sweep16_fn at_pick16(int kmode, int g, int k, int ts, int store, bool tb)
 {
-	if (g == 16) return at_pick16_g16(kmode, k, store, tb);
-	switch (kmode) {
-	case at::K_GLOBAL: return p2<at::K_GLOBAL>(k, store, tb);
-	case at::K_LOCAL: return p2<at::K_LOCAL>(k, store, tb);
-	case at::K_FITJ: return p2<at::K_FITJ>(k, store, tb);
-	default: return p2<at::K_FIT>(k, store, tb);
-	}
+	if (g == 16) return ts == 4 ? at_pick16_g16(kmode, k, store, tb) : nullptr;
+	return ts == 4 ? at_pick16_g64_ts4(kmode, k, store, tb) : at_pick16_g64_ts2(kmode, k, store, tb);
 }

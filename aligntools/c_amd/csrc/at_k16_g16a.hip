@@ -4,9 +4,9 @@
 template <int MODE, int K>
 static at_sweep16_fn q3(int store, bool tb)
 {
-	if (!tb) return at::at_sweep16<MODE, 16, K, true, true, false>;
-	if (store == 0) return at::at_sweep16<MODE, 16, K, true, true, true>;
-	return at::at_sweep16<MODE, 16, K, true, false, true>;
+	if (!tb) return at::at_sweep16<MODE, 16, K, 4, true, true, false>;
+	if (store == 0) return at::at_sweep16<MODE, 16, K, 4, true, true, true>;
+	return at::at_sweep16<MODE, 16, K, 4, true, false, true>;
 }
 template <int MODE>
 static at_sweep16_fn q2(int k, int store, bool tb)

@@ -22,7 +22,11 @@
  * reads the 16-bit scores of both pairs from a byte LUT {m,u,u,u}.
  *
  * Tags, pointer bits and tie-breaking are exactly those of at_sweep.hip.h,
- * per 16-bit half (reference max5 first-wins order, alignment.h:90-100).
+ * per 16-bit half (reference max5 first-wins order, alignment.h:90-100), when
+ * TS = 4 (scores scaled by 16, |score| < 2048).  TS = 2 trades pointer bits for
+ * range: scores scaled by 4 (|score| < 8192, e.g. 1024 x 1024 global), tags
+ * L 3 / M 2 / U 1 / J,HOME 0; the pointer nibble then takes bit 0 of the L and U
+ * winners' tags (two packed shifts more than TS = 4).
  * Local arg-max (alignment.h:830-833, first in row-major order) is tracked
  * once per step: the K cells of the column are reduced with the row index in
  * the (otherwise constant) tag bits, then folded into a per-lane running
@@ -73,6 +77,11 @@ AT_DEV uint32_t pshl4(uint32_t a)
 {
 	return __builtin_bit_cast(uint32_t, __builtin_bit_cast(s16x2, a) << (s16x2)(4));
 }
+template <int N>
+AT_DEV uint32_t pshln(uint32_t a)
+{
+	return __builtin_bit_cast(uint32_t, __builtin_bit_cast(s16x2, a) << (s16x2)(N));
+}
 AT_DEV uint32_t pshl8(uint32_t a)
 {
 	return __builtin_bit_cast(uint32_t, __builtin_bit_cast(s16x2, a) << (s16x2)(8));
@@ -117,12 +126,15 @@ AT_DEV uint32_t grp_up1(uint32_t old, uint32_t src)
 	else return (uint32_t)__builtin_amdgcn_update_dpp((int)old, (int)src, 0x111 /* row_shr:1 */, 0xf, 0xf, false);
 }
 
-template <int MODE, int G, int K, bool SMALL, bool PTRLDS, bool TB>
+template <int MODE, int G, int K, int TS, bool SMALL, bool PTRLDS, bool TB>
 __global__ __launch_bounds__(64, AT_WAVES16(G, K)) void at_sweep16(const Sweep16Args a)
 {
 	static_assert(MODE == K_GLOBAL || MODE == K_LOCAL || MODE == K_FIT || MODE == K_FITJ, "packed path: the affine modes");
 	constexpr bool HASJ = MODE == K_FITJ;
 	constexpr bool ISFIT = MODE == K_FIT || MODE == K_FITJ;
+	static_assert(TS == 4 || (TS == 2 && K <= 4), "TS = 2: the local row tag must fit 2 bits");
+	constexpr int TMASK = (1 << TS) - 1;      /* tag bits of a score */
+	constexpr int TGL = TS == 4 ? 15 : 3, TGM = TS == 4 ? 10 : 2, TGU = 1;
 	constexpr int PB = HASJ ? 8 : 4;          /* pointer bits per cell and alignment */
 	constexpr int SPW = 16 / PB;              /* steps per pointer word (each half holds its own alignment) */
 	static_assert(G == 64 || G == 16, "group width");
@@ -148,8 +160,10 @@ __global__ __launch_bounds__(64, AT_WAVES16(G, K)) void at_sweep16(const Sweep16
 	uint32_t lut_lo = ((uint32_t)a.m16 & 0xffu) | (((uint32_t)a.u16 & 0xffu) * 0x01010100u);
 	uint32_t lut_hi = (((uint32_t)a.m16 >> 8) & 0xffu) | ((((uint32_t)a.u16 >> 8) & 0xffu) * 0x01010100u);
 	/* constants live in VGPRs: VOP3 encodings take no 32-bit literals, and a literal would split and_or into two ops */
-	uint32_t cClean = kClean2, cTagM = kTagM2, cTagL = kTagL2, cTagU = kTagU2;
-	uint32_t cM3 = 0x00030003u, cM7 = 0x00070007u, cNib = 0x000f000fu, c8 = 0x00080008u;
+	uint32_t cClean = (uint32_t)(0xffff & ~TMASK) * 0x00010001u, cTagM = (uint32_t)TGM * 0x00010001u;
+	uint32_t cTagL = (uint32_t)TGL * 0x00010001u, cTagU = (uint32_t)TGU * 0x00010001u;
+	uint32_t cM3 = 0x00030003u, cM7 = 0x00070007u, cNib = 0x000f000fu;
+	uint32_t c8 = TS == 4 ? 0x00080008u : 0x00020002u;   /* the bit of the J winner's tag that tells M (open) from J */
 	/* jump state: J(i,j) = max(M(i,j-1) + g, J(i,j-1)) where the column may open, else J(i,j-1) (alignment.h:658-666);
 	 * the left state holds M + o, so the opening candidate is (M + o) + (g - o), or -inf where opening is barred */
 	uint32_t gmo2 = pk2(a.g16 - a.o16), neg2 = 0x80008000u;
@@ -194,8 +208,8 @@ __global__ __launch_bounds__(64, AT_WAVES16(G, K)) void at_sweep16(const Sweep16
 		for (int j = lane; j <= l2; j += 64) {
 			int L, M, U;
 			border16<MODE>(0, j, o16, e16, L, M, U);
-			const int x = imax3(L | kTagL, M | kTagM, U | kTagU);
-			const int ld = imax(sat16((L | kTagL) + e16), sat16((M | kTagM) + o16));
+			const int x = imax3(L | TGL, M | TGM, U | TGU);
+			const int ld = imax(sat16((L | TGL) + e16), sat16((M | TGM) + o16));
 			mem.st2(a.off_bound + 2 * j, pk2(x), pk2(ld));
 		}
 		mem.sync();
@@ -222,22 +236,22 @@ __global__ __launch_bounds__(64, AT_WAVES16(G, K)) void at_sweep16(const Sweep16
 				acc[r] = 0;
 				/* rows past l1 (only in the last lane that owns rows): their key collapses to the bare row tag,
 				 * which every real row of the lane beats (smaller r = larger tag, score >= 0) */
-				keymask[r] = i0 + r < l1 ? kClean2 : 0u;
+				keymask[r] = i0 + r < l1 ? (uint32_t)(0xffff & ~TMASK) * 0x00010001u : 0u;
 				int L, M, U;
 				border16<MODE>(i0 + r + 1, 0, o16, e16, L, M, U);
 				L = sat16(L);
-				Mo_l[r] = pk2(sat16((M | kTagM) + o16));
-				U_l[r] = pk2(U | kTagU);
-				L_l[r] = pk2(L | kTagL);
+				Mo_l[r] = pk2(sat16((M | TGM) + o16));
+				U_l[r] = pk2(U | TGU);
+				L_l[r] = pk2(L | TGL);
 				J_l[r] = neg2;                    /* J is -inf on both borders (:616, :622) */
-				Xl[r] = pk2(imax3(L | kTagL, M | kTagM, U | kTagU));
+				Xl[r] = pk2(imax3(L | TGL, M | TGM, U | TGU));
 			}
 			uint32_t A_prev = Xl[K - 1], B_prev = 0, Ad;
 			{
 				int L, M, U;
 				border16<MODE>(base, 0, o16, e16, L, M, U);
 				L = sat16(L);
-				Ad = pk2(imax3(L | kTagL, M | kTagM, U | kTagU));
+				Ad = pk2(imax3(L | TGL, M | TGM, U | TGU));
 			}
 			uint32_t best = 0x80008000u, bt = 0;   /* local: per-lane (key, step) of this strip */
 			auto load_bound = [&](int t0, uint32_t &bx, uint32_t &bl) {
@@ -333,15 +347,28 @@ __global__ __launch_bounds__(64, AT_WAVES16(G, K)) void at_sweep16(const Sweep16
 							}
 							const uint32_t Ld = pmax(padd(Lc, e2), Mo);
 							if constexpr (TB) {
-								uint32_t nib = vbfi(cM3, Mraw, lraw);
-								nib = vbfi(cM7, nib, Uraw);
-								if constexpr (HASJ) {
-									/* 5 bits: the nibble plus bit 4 = J came from M; two steps per 16-bit half */
-									nib = ((Jraw & c8) << 1) | (nib & cNib);
-									acc[r] = pshl8(acc[r]) | nib;
+								if constexpr (TS == 4) {
+									uint32_t nib = vbfi(cM3, Mraw, lraw);
+									nib = vbfi(cM7, nib, Uraw);
+									if constexpr (HASJ) {
+										/* 5 bits: the nibble plus bit 4 = J came from M; two steps per 16-bit half */
+										nib = ((Jraw & c8) << 1) | (nib & cNib);
+										acc[r] = pshl8(acc[r]) | nib;
+									} else {
+										/* each half keeps its own 4-step shift register: acc = acc << 4 | nibble */
+										acc[r] = vandor(nib, cNib, pshl4(acc[r]));
+									}
 								} else {
-									/* each half keeps its own 4-step shift register: acc = acc << 4 | nibble */
-									acc[r] = vandor(nib, cNib, pshl4(acc[r]));
+									/* 2-bit tags: bit 0 of the L winner (3 ext / 2 open) and of the U winner (1 ext / 2 open)
+									 * carry the choice: nibble = {U tag bit 0, L tag bit 0, pM[1:0]} (+ bit 4: J tag bit 1) */
+									uint32_t nib = vbfi(cM3, Mraw, pshln<2>(lraw));
+									nib = vbfi(cM7, nib, pshln<3>(Uraw));
+									if constexpr (HASJ) {
+										nib = ((Jraw & c8) << 3) | (nib & cNib);
+										acc[r] = pshl8(acc[r]) | nib;
+									} else {
+										acc[r] = vandor(nib, cNib, pshl4(acc[r]));
+									}
 								}
 							}
 							if constexpr (MODE == K_LOCAL) {
@@ -369,7 +396,7 @@ __global__ __launch_bounds__(64, AT_WAVES16(G, K)) void at_sweep16(const Sweep16
 					else if constexpr (TB && masked) {
 						/* keep the shift registers in step: nibble k of a word is always step k of its 4-step group */
 #pragma unroll
-						for (int r = 0; r < K; ++r) acc[r] = HASJ ? pshl8(acc[r]) : pshl4(acc[r]);
+						for (int r = 0; r < K; ++r) acc[r] = PB == 8 ? pshl8(acc[r]) : pshl4(acc[r]);
 					}
 					Ad = Aup;
 					if constexpr (TB) {
@@ -399,8 +426,8 @@ __global__ __launch_bounds__(64, AT_WAVES16(G, K)) void at_sweep16(const Sweep16
 #pragma unroll
 				for (int h = 0; h < 2; ++h) {
 					const int key = half(best, h);
-					const int sc = key & ~15;
-					const int row = i0 + (K - 1 - (key & 15)) + 1;
+					const int sc = key & ~TMASK;
+					const int row = i0 + (K - 1 - (key & TMASK)) + 1;
 					if (key != kNeg16 && row <= l1 && sc > gbs[h]) {
 						gbs[h] = sc;
 						gbi[h] = row;
@@ -444,7 +471,7 @@ __global__ __launch_bounds__(64, AT_WAVES16(G, K)) void at_sweep16(const Sweep16
 				const int bL = half((uint32_t)__builtin_amdgcn_readlane((int)bestL, own), h);
 				const int jL = half((uint32_t)__builtin_amdgcn_readlane((int)bestLj, own), h);
 				ci = l1;
-				if ((bL >> kShift) > (bM >> kShift) && bL > a.thresh16) { sc16 = bL; st = 3; cj = jL; }
+				if ((bL >> TS) > (bM >> TS) && bL > a.thresh16) { sc16 = bL; st = 3; cj = jL; }
 				else { sc16 = bM; st = 2; cj = jM; }
 				ok = sc16 > a.thresh16;
 			}
@@ -473,10 +500,15 @@ __global__ __launch_bounds__(64, AT_WAVES16(G, K)) void at_sweep16(const Sweep16
 							const uint32_t w = pm.ld(a.off_ptr + (ss * wps + (t / SPW) * K + r) * NL + glane + ln);
 							const uint32_t nb = (w >> (16 * h + PB * (SPW - 1 - (t % SPW)))) & ((1u << PB) - 1u);
 							int op;
-							if (st == 3) { st = (nb & 4u) ? 3 : 2; op = 1; --ci; }
+							/* nibble {bit 3: U winner, bit 2: L winner, pM[1:0]} (+ bit 4: J came from M).  Bit 3 is bit 3 of the
+							 * winner's tag for TS = 4 (M's 10 has it) and bit 0 for TS = 2 (U's 1 has it). */
+							const bool l_ext = (nb & 4u) != 0;
+							const bool u_open = TS == 4 ? (nb & 8u) != 0 : (nb & 8u) == 0;
+							const bool j_open = (nb & 16u) != 0;
+							if (st == 3) { st = l_ext ? 3 : 2; op = 1; --ci; }
 							else if (st == 2) { st = (int)(nb & 3u); op = 0; --ci; --cj; }
-							else if (st == 1) { st = (nb & 8u) ? 2 : 1; op = 2; --cj; }
-							else if (HASJ) { st = (nb & 16u) ? 2 : 0; op = 3; --cj; }       /* jump state :579-583 */
+							else if (st == 1) { st = u_open ? 2 : 1; op = 2; --cj; }
+							else if (HASJ) { st = j_open ? 2 : 0; op = 3; --cj; }       /* jump state :579-583 */
 							else { ok = false; break; }
 							ops[cnt++] = (uint8_t)op;
 						}
@@ -487,7 +519,7 @@ __global__ __launch_bounds__(64, AT_WAVES16(G, K)) void at_sweep16(const Sweep16
 						if (guard < 0) ok = false;
 					}
 				}
-				a.score[p] = ok ? (my_sc >> kShift) : INT32_MIN;
+				a.score[p] = ok ? (my_sc >> TS) : INT32_MIN;
 				if (a.end_i) a.end_i[p] = my_ci;
 				if (a.end_j) a.end_j[p] = my_cj;
 				if (a.state) a.state[p] = my_st == 3 ? 1 : my_st == 2 ? 2 : 3;

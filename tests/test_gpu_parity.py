@@ -22,7 +22,9 @@ def _md5(s):
 
 @pytest.fixture(scope="module")
 def al():
+    import os
     import aligntools.c_amd as A
+    os.environ["AT_PACKED_MIN_ROUNDS"] = "0"   # small test batches must still reach the 64-lane packed kernels
     a = A.Aligner()
     yield a
     a.close()
@@ -235,7 +237,7 @@ def test_packed16_score_range_extremes(al, mode):
     range the host admits -- all-mismatch and all-match pairs, one-sided gaps, the largest eligible
     shape (two strips of 4 rows per lane) -- and require exact agreement with the fp64 oracle."""
     rng = random.Random(2026)
-    for (l1, l2) in [(150, 150), (200, 208), (330, 330), (100, 500)]:
+    for (l1, l2) in [(150, 150), (200, 208), (330, 330), (100, 500), (600, 640), (1024, 1024)]:
         if mode != "fit" and (l1, l2) == (100, 500):
             continue
         a_run, c_run = "A" * l1, "C" * l2
@@ -246,11 +248,13 @@ def test_packed16_score_range_extremes(al, mode):
                  (rnd1, (rnd1[l1 // 2:] + rnd1 * 4)[:l2]),         # a long gap first
                  ("AC" * (l1 // 2) + "A" * (l1 % 2), ("CA" * l2)[:l2]),   # tie-heavy periodic
                  (a_run, ("C" * (l2 // 2) + "A" * l2)[:l2])]
-        for sc in ((2, -2, -5, -2), (1, -2, -5, -1)):
+        for sc in ((2, -2, -5, -2), (1, -2, -5, -1), (1, -1, -4, -1)):
             al.set_scoring(*sc)
             res = al.align_batch(mode, pairs)
             if "packed16" not in al.last_config:                  # shape/scoring not admitted: nothing to test here
                 continue
+            if (l1, l2) == (1024, 1024) and sc == (1, -1, -4, -1):
+                assert "packed16 x4" in al.last_config             # scores x4, byte pointers (at_sweep16 TS = 2)
             for k, (s1, s2) in enumerate(pairs):
                 r = O.align(O.MODE_NAMES[mode], s1, s2, *sc)
                 assert r["rc"] == 0

@@ -13,6 +13,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <functional>
 #include <string>
 #include <vector>
 
@@ -365,7 +366,7 @@ struct Plan {
 };
 
 static int plan_launch(at_handle *h, const char *tag, int k, long long nwork, long long words_fixed, long long words_ptr,
-                       Plan *pl, hipStream_t stream)
+                       Plan *pl, hipStream_t stream, const std::function<const void *(int)> &kernel_for_store)
 {
 	/* all-LDS only while at least 8 waves (2 per SIMD) still fit a CU: measured, occupancy beyond 1 wave/SIMD is
 	 * worth +30..50 % on this issue-bound kernel (profiles/r01) */
@@ -385,7 +386,15 @@ static int plan_launch(at_handle *h, const char *tag, int k, long long nwork, lo
 	long long per_cu = 16;
 	if (lds_words > 0) per_cu = std::min<long long>(per_cu, (long long)(h->lds_per_cu - 512) / std::max<long long>(lds_words * 4, 256));
 	per_cu = std::max(1LL, std::min(per_cu, env_ll("AT_WAVES_PER_CU", 16)));
+	{   /* what the register file really admits */
+		int occ = 0;
+		const void *fn = kernel_for_store ? kernel_for_store(store) : nullptr;
+		if (fn && hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, fn, 64, (size_t)lds_words * 4) == hipSuccess && occ > 0)
+			per_cu = std::min<long long>(per_cu, occ);
+	}
 	long long grid = std::max(1LL, std::min<long long>(nwork, per_cu * h->ncu));
+	/* (Tried and dropped: shrinking the grid so that every wave gets the same number of items -- fewer resident
+	 * waves cost 5-13 % more than the partial last round they avoid.) */
 	pl->store = store;
 	pl->off_ptr = store == 1 ? 0 : (int)words_fixed;
 	pl->dyn_lds = (size_t)lds_words * 4;
@@ -517,7 +526,8 @@ static int align_device(at_handle *h, int mode, int64_t npairs,
 		const int per_wave = 2 * (64 / P.g);
 		char tag16[64];
 		snprintf(tag16, sizeof tag16, "packed16 x%d %dx%d-lane groups (%d pairs/wave)", 1 << ts, 64 / P.g, P.g, per_wave);
-		int rc = plan_launch(h, tag16, P.k, (npairs + per_wave - 1) / per_wave, P.off_ptr, P.words - P.off_ptr, &pl, stream);
+		int rc = plan_launch(h, tag16, P.k, (npairs + per_wave - 1) / per_wave, P.off_ptr, P.words - P.off_ptr, &pl, stream,
+		                     [&](int st) { return (const void *)at_pick16(kmode, P.g, P.k, ts, st, tb); });
 		if (rc) return rc;
 		b.off_ptr = pl.off_ptr; b.ws = pl.ws; b.ws_slot_words = pl.slot_words; b.queue = h->d_queue;
 		at_sweep16_fn fn16 = at_pick16(kmode, P.g, P.k, ts, pl.store, tb);
@@ -553,7 +563,9 @@ static int align_device(at_handle *h, int mode, int64_t npairs,
 	Plan pl;
 	char tag[32];
 	snprintf(tag, sizeof tag, "int32 bits=%d", bits);
-	int rc = plan_launch(h, tag, L.k, npairs, L.off_ptr, L.words - L.off_ptr, &pl, stream);
+	int rc = plan_launch(h, tag, L.k, npairs, L.off_ptr, L.words - L.off_ptr, &pl, stream, [&](int st) {
+		return (const void *)(bits == 2 ? at_pick32_b2(kmode, L.k, st, tb) : at_pick32_b8(kmode, L.k, st, tb));
+	});
 	if (rc) return rc;
 	a.off_ptr = pl.off_ptr; a.ws = pl.ws; a.ws_slot_words = pl.slot_words; a.queue = h->d_queue;
 	at_sweep_fn fn = bits == 2 ? at_pick32_b2(kmode, L.k, pl.store, tb) : at_pick32_b8(kmode, L.k, pl.store, tb);

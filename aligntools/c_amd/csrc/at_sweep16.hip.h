@@ -217,7 +217,9 @@ __global__ __launch_bounds__(64, AT_WAVES16(G, K)) void at_sweep16(const Sweep16
 		/* running results, per half */
 		int gbi[2] = {INT32_MAX, INT32_MAX}, gbj[2] = {INT32_MAX, INT32_MAX}, gbs[2] = {INT32_MIN, INT32_MIN};
 		uint32_t bestM = pk2(a.thresh16), bestMj = 0, bestL = pk2(a.thresh16), bestLj = 0;   /* fit scans */
-		uint32_t Mo_l[K], U_l[K], Xl[K], L_l[K], J_l[K];
+		/* Xl: X' of my rows at the previous column (the diagonal input of the row below).  Two copies used in turn
+		 * (step parity), so that the old value can be read while the new one is written without register moves. */
+		uint32_t Mo_l[K], U_l[K], Xl[2][K], L_l[K], J_l[K];
 
 		for (int s = 0; s < nstrips; ++s) {
 			const int base = s * RS;
@@ -244,9 +246,10 @@ __global__ __launch_bounds__(64, AT_WAVES16(G, K)) void at_sweep16(const Sweep16
 				U_l[r] = pk2(U | TGU);
 				L_l[r] = pk2(L | TGL);
 				J_l[r] = neg2;                    /* J is -inf on both borders (:616, :622) */
-				Xl[r] = pk2(imax3(L | TGL, M | TGM, U | TGU));
+				Xl[0][r] = pk2(imax3(L | TGL, M | TGM, U | TGU));
+				Xl[1][r] = Xl[0][r];
 			}
-			uint32_t A_prev = Xl[K - 1], B_prev = 0, Ad;
+			uint32_t A_prev = Xl[0][K - 1], B_prev = 0, Ad;
 			{
 				int L, M, U;
 				border16<MODE>(base, 0, o16, e16, L, M, U);
@@ -376,8 +379,8 @@ __global__ __launch_bounds__(64, AT_WAVES16(G, K)) void at_sweep16(const Sweep16
 								const uint32_t key = (Mraw & keymask[r]) | rt;
 								cmax = r == 0 ? key : pmax(cmax, key);
 							}
-							diag = Xl[r];
-							Xl[r] = Xo;
+							diag = Xl[k & 1][r];
+							Xl[(k & 1) ^ 1][r] = Xo;
 							lraw = Ld;
 							up = Xo;
 							Mo_l[r] = Mo; U_l[r] = Uc;
@@ -394,7 +397,9 @@ __global__ __launch_bounds__(64, AT_WAVES16(G, K)) void at_sweep16(const Sweep16
 						if (wb && lane == 63) mem.st2(a.off_bound + 2 * (jm1 + 1), up, lraw);
 					}
 					else if constexpr (TB && masked) {
-						/* keep the shift registers in step: nibble k of a word is always step k of its 4-step group */
+						/* keep the shift registers in step: nibble k of a word is always step k of its 4-step group.
+						 * (Xl needs nothing here: a lane is active for one contiguous run of steps, both copies start out
+						 * holding the column-0 values, and nothing is read after the run.) */
 #pragma unroll
 						for (int r = 0; r < K; ++r) acc[r] = PB == 8 ? pshl8(acc[r]) : pshl4(acc[r]);
 					}

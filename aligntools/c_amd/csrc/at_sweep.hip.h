@@ -329,7 +329,10 @@ __global__ __launch_bounds__(64) void at_sweep(const SweepArgs a)
 		int best = INT32_MIN, best_i = INT32_MAX, best_j = INT32_MAX;   /* local arg-max; fit/overlap: last-row M scan */
 		int bestL = kNegThresh, bestL_j = 0;                            /* fit: last-row L scan                        */
 		if constexpr (MODE == K_FIT || MODE == K_FITJ) best = kNegThresh;
-		int Mo_l[K], U_l[K], Xl[K], L_l[K], Mg_l[K], J_l[K];   /* per-row left state (registers) */
+		/* per-row left state (registers).  Xl = X' of my rows at the previous column, kept in two copies used in turn by
+		 * step parity: the old value is read while the new one is written, without register moves.  (A lane is active
+		 * for one contiguous run of steps and both copies start with the column-0 value, so inactive steps touch nothing.) */
+		int Mo_l[K], U_l[K], Xl[2][K], L_l[K], Mg_l[K], J_l[K];
 
 		for (int s = 0; s < nstrips; ++s) {
 			const int base = s * RS;
@@ -355,7 +358,8 @@ __global__ __launch_bounds__(64) void at_sweep(const SweepArgs a)
 					U_l[r] = U | kTagU;
 					J_l[r] = J;
 					L_l[r] = L | kTagL;
-					Xl[r] = xo_of<MODE>(L, M, U, J);
+					Xl[0][r] = xo_of<MODE>(L, M, U, J);
+					Xl[1][r] = Xl[0][r];
 				} else if constexpr (MODE == K_OVERLAP) {
 					Mo_l[r] = o16;           /* M(i,0) = 0 -> P = M + o */
 				} else {
@@ -365,7 +369,7 @@ __global__ __launch_bounds__(64) void at_sweep(const SweepArgs a)
 			/* what the lane below sees as "row above, column 0", and my own diagonal */
 			int A_prev, B_prev = 0, Ad;
 			if constexpr (AFFINE) {
-				A_prev = Xl[K - 1];
+				A_prev = Xl[0][K - 1];
 				int L, M, U, J;
 				border<MODE>(base, 0, o16, e16, L, M, U, J);
 				Ad = xo_of<MODE>(L, M, U, J);
@@ -482,8 +486,8 @@ __global__ __launch_bounds__(64) void at_sweep(const SweepArgs a)
 									if (Mc > best_r[r]) { best_r[r] = Mc; bt_r[r] = t; }   /* :830-833 */
 								}
 								/* hand down / right */
-								diag = Xl[r];
-								Xl[r] = Xo;
+								diag = Xl[k & 1][r];
+								Xl[(k & 1) ^ 1][r] = Xo;
 								lraw = Ld;
 								up = Xo;
 								Mo_l[r] = Mo; U_l[r] = Uc;

@@ -212,7 +212,7 @@ def main():
                       else "GCUPS (DP cell updates/s), %s %dx%d" % (mode, l1, l2),
             "value": gcups, "unit": "GCUPS", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "int32", "data": "synthetic",
+            "vs_baseline": None, "dtype": "int16" if "packed16" in al.last_config else "int32", "data": "synthetic",
             "config": {"workload": "%s: %s affine-gap, %d x (%dx%d bp) pairs per GPU, uniform ACGT, m=%d u=%d o=%d e=%d%s, "
                                    "%s" % (args.workload, mode, pairs, l1, l2, m, u, o, e, " j=%d -s" % j if uj else "",
                                            "scores+tracebacks" if tb else "scores only"),
@@ -224,7 +224,7 @@ def main():
                          "kernel_avg_ms": kern_avg_ms,
                          "kernel_min_ms": kern_ms[0], "algorithmic_bytes_per_launch": bytes_in + bytes_out,
                          "note": "integer max/add DP: the binding resource is VALU issue, not HBM (DESIGN.md section 4; "
-                                 "profiles/traffic_C2.json holds the SQ counters: 88 % of the measured half-rate issue bound)",
+                                 "profiles/traffic_C2.json holds the SQ counters and the issue-bound model)",
                          "valu_gcups_kernel": float(pairs) * l1 * l2 / (kern_avg_ms * 1e-3) / 1e9},
             "cpu_baseline": base,
         }

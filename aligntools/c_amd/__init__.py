@@ -24,8 +24,9 @@ ST_LOW, ST_MID, ST_UPP = 1, 2, 3
 
 # every symbol include/aligntools_hip.h declares
 ABI_SYMBOLS = ["at_init", "at_destroy", "at_last_error", "at_set_scoring", "at_align_batch",
-               "at_align_batch_device", "at_align_allpairs_device", "at_pack_words", "at_pack_batch", "at_render",
-               "at_last_config"]
+               "at_align_batch_device", "at_align_allpairs_device", "at_render_batch_device", "at_compact_ops_device",
+               "at_align_batch_strings",
+               "at_pack_words", "at_pack_batch", "at_render", "at_last_config"]
 
 _i32p = C.POINTER(C.c_int32)
 _i64p = C.POINTER(C.c_int64)
@@ -72,6 +73,13 @@ def load_library():
     lib.at_align_allpairs_device.argtypes = [C.c_void_p, C.c_int, C.c_int64, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p,
                                              C.c_int32, C.c_int64, C.c_int64, C.c_int, C.c_void_p, C.c_void_p,
                                              C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+    lib.at_render_batch_device.restype = C.c_int
+    lib.at_render_batch_device.argtypes = [C.c_void_p, C.c_int64, C.c_void_p, C.c_int] + [C.c_void_p] * 10 + [C.c_int, C.c_void_p]
+    lib.at_compact_ops_device.restype = C.c_int
+    lib.at_compact_ops_device.argtypes = [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64,
+                                          C.c_void_p, C.c_void_p]
+    lib.at_align_batch_strings.restype = C.c_int
+    lib.at_align_batch_strings.argtypes = [C.c_void_p, C.c_int, C.c_int64] + [C.c_void_p] * 13
     lib.at_pack_words.restype = C.c_int64
     lib.at_pack_words.argtypes = [C.c_int64, C.c_void_p, C.c_void_p, C.c_int]
     lib.at_pack_batch.restype = C.c_int
@@ -176,10 +184,45 @@ class Aligner:
     def set_opt(self, opt):
         self.set_scoring(opt.m, opt.u, opt.o, opt.e, opt.j, opt.s, opt.sites)
 
+    def align_batch_strings(self, mode, pairs):
+        """pairs: list of (s1, s2) bytes/str.  The two gapped strings of every pair, rendered on the GPU
+        (at_align_batch_strings).  Returns a dict: score, end_i, end_j, state, nops (numpy) and r1, r2 (lists of str)."""
+        if isinstance(mode, str):
+            mode = MODES[mode]
+        pairs = [(_b(a), _b(b)) for a, b in pairs]
+        n = len(pairs)
+        blob, off1, len1, off2, len2 = _flatten(pairs)
+        score, end_i, end_j, state, nops = (np.zeros(n, dtype=np.int32) for _ in range(5))
+        str_off = off1 + np.arange(n, dtype=np.int64)          # slots of l1+l2+1 bytes
+        total = int(len(blob) + n + 64)
+        r1 = np.zeros(total, dtype=np.uint8)
+        r2 = np.zeros(total, dtype=np.uint8)
+        self._check(self._lib.at_align_batch_strings(self._h, mode, n, _ptr(blob), _ptr(off1), _ptr(len1), _ptr(off2),
+                                                     _ptr(len2), _ptr(score), _ptr(end_i), _ptr(end_j), _ptr(state),
+                                                     _ptr(r1), _ptr(r2), _ptr(str_off), _ptr(nops)))
+        b1, b2 = r1.tobytes(), r2.tobytes()
+        out = dict(score=score, end_i=end_i, end_j=end_j, state=state, nops=nops)
+        out["r1"] = [b1[str_off[k]:str_off[k] + nops[k]].decode("latin1") for k in range(n)]
+        out["r2"] = [b2[str_off[k]:str_off[k] + nops[k]].decode("latin1") for k in range(n)]
+        return out
+
+    def render_batch_device(self, npairs, d_seq, bits, d_woff1, d_woff2, d_end_i, d_end_j, d_ops, d_ops_off, d_nops,
+                            d_r1, d_r2, d_str_off=None, nul_terminate=False, stream=0):
+        """Raw device-pointer entry of the rendering kernel (at_render_batch_device)."""
+        self._check(self._lib.at_render_batch_device(self._h, npairs, d_seq, bits, d_woff1, d_woff2, d_end_i, d_end_j,
+                                                     d_ops, d_ops_off, d_nops, d_r1, d_r2, d_str_off,
+                                                     1 if nul_terminate else 0, stream))
+
+    def compact_ops_device(self, npairs, d_ops, d_ops_off, d_nops, d_packed, packed_cap, d_packed_off, stream=0):
+        """Slots of ops -> one contiguous payload + exclusive offsets (at_compact_ops_device)."""
+        self._check(self._lib.at_compact_ops_device(self._h, npairs, d_ops, d_ops_off, d_nops, d_packed, packed_cap,
+                                                    d_packed_off, stream))
+
     def align_batch(self, mode, pairs, traceback=True, render=True):
         """pairs: list of (s1, s2) bytes/str.  Returns a dict of numpy arrays
         (score, end_i, end_j, state, nops), `ops` (list of bytes, END->START) and,
-        with render, `r1`/`r2` (the reference's two gapped strings)."""
+        with render, `r1`/`r2` (the reference's two gapped strings, rendered on the host by at_render;
+        align_batch_strings renders them on the GPU)."""
         if isinstance(mode, str):
             mode = MODES[mode]
         pairs = [(_b(a), _b(b)) for a, b in pairs]

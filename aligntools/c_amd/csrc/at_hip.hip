@@ -6,6 +6,7 @@
  */
 #include "at_launch.h"
 #include "at_pack.hip.h"
+#include "at_render.hip.h"
 #include "../../../include/aligntools_hip.h"
 
 #include <algorithm>
@@ -36,6 +37,9 @@ struct at_handle {
 	void *d_out = nullptr; size_t out_bytes = 0;
 	void *d_desc = nullptr; size_t desc_bytes = 0;
 	void *d_order = nullptr; size_t order_bytes = 0;
+	void *d_str = nullptr; size_t str_bytes = 0;
+	void *d_scan = nullptr; size_t scan_bytes = 0;
+	int *d_rflag = nullptr;         /* at_render_k's "op list walks off its sequences" flag */
 	char err[512] = {0};
 	char cfg[320] = "none";
 };
@@ -87,6 +91,8 @@ extern "C" int at_init(const int *device_ids, int n_devices, at_handle **out)
 	h->ncu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
 	if (prop.maxSharedMemoryPerMultiProcessor > 0) h->lds_per_cu = prop.maxSharedMemoryPerMultiProcessor;
 	HIP_TRY(h, hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
+	HIP_TRY(h, hipMalloc((void **)&h->d_rflag, 256));
+	HIP_TRY(h, hipMemset(h->d_rflag, 0, 256));
 	h->err[0] = 0;
 	*out = h;
 	return AT_OK;
@@ -103,6 +109,9 @@ extern "C" void at_destroy(at_handle *h)
 	if (h->d_out) (void)hipFree(h->d_out);
 	if (h->d_desc) (void)hipFree(h->d_desc);
 	if (h->d_order) (void)hipFree(h->d_order);
+	if (h->d_str) (void)hipFree(h->d_str);
+	if (h->d_scan) (void)hipFree(h->d_scan);
+	if (h->d_rflag) (void)hipFree(h->d_rflag);
 	if (h->stream) (void)hipStreamDestroy(h->stream);
 	delete h;
 }
@@ -456,6 +465,61 @@ extern "C" int at_align_allpairs_device(at_handle *h, int mode, int64_t nreads,
 	                    d_score, d_end_i, d_end_j, d_state, d_ops, d_ops_off, d_nops, stream_, nreads, first_pair);
 }
 
+extern "C" int at_render_batch_device(at_handle *h, int64_t npairs,
+                                      const uint32_t *d_seq, int bits,
+                                      const int64_t *d_woff1, const int64_t *d_woff2,
+                                      const int32_t *d_end_i, const int32_t *d_end_j,
+                                      const uint8_t *d_ops, const int64_t *d_ops_off, const int32_t *d_nops,
+                                      uint8_t *d_r1, uint8_t *d_r2, const int64_t *d_str_off, int nul_terminate,
+                                      void *stream_)
+{
+	if (!h) return fail(nullptr, AT_ERR_ARG, "at_render_batch_device: NULL handle");
+	if (npairs < 0) return fail(h, AT_ERR_ARG, "negative npairs");
+	if (npairs == 0) return AT_OK;
+	if (bits != 2 && bits != 8) return fail(h, AT_ERR_ARG, "bits must be 2 or 8");
+	if (!d_seq || !d_woff1 || !d_woff2 || !d_end_i || !d_end_j || !d_ops || !d_ops_off || !d_nops || !d_r1 || !d_r2)
+		return fail(h, AT_ERR_ARG, "NULL device pointer");
+	HIP_TRY(h, hipSetDevice(h->device));
+	hipStream_t s = (hipStream_t)stream_;
+	at::RenderArgs ra;
+	ra.npairs = npairs; ra.seq = d_seq; ra.woff1 = (const long long *)d_woff1; ra.woff2 = (const long long *)d_woff2;
+	ra.end_i = d_end_i; ra.end_j = d_end_j; ra.ops = d_ops; ra.ops_off = (const long long *)d_ops_off; ra.nops = d_nops;
+	ra.r1 = d_r1; ra.r2 = d_r2; ra.str_off = (const long long *)d_str_off; ra.nul = nul_terminate ? 1 : 0; ra.bad = h->d_rflag;
+	const unsigned grid = (unsigned)std::min<int64_t>((npairs + 3) / 4, 16LL * h->ncu);
+	if (bits == 2) hipLaunchKernelGGL(at::at_render_k<2>, dim3(grid), dim3(256), 0, s, ra);
+	else hipLaunchKernelGGL(at::at_render_k<8>, dim3(grid), dim3(256), 0, s, ra);
+	HIP_TRY(h, hipGetLastError());
+	return AT_OK;
+}
+
+extern "C" int at_compact_ops_device(at_handle *h, int64_t npairs,
+                                     const uint8_t *d_ops, const int64_t *d_ops_off, const int32_t *d_nops,
+                                     uint8_t *d_packed, int64_t packed_cap, int64_t *d_packed_off, void *stream_)
+{
+	if (!h) return fail(nullptr, AT_ERR_ARG, "at_compact_ops_device: NULL handle");
+	if (npairs < 0 || packed_cap < 0) return fail(h, AT_ERR_ARG, "negative size");
+	if (!d_ops || !d_ops_off || !d_nops || !d_packed || !d_packed_off) return fail(h, AT_ERR_ARG, "NULL device pointer");
+	HIP_TRY(h, hipSetDevice(h->device));
+	hipStream_t s = (hipStream_t)stream_;
+	if (npairs == 0) {
+		HIP_TRY(h, hipMemsetAsync(d_packed_off, 0, 8, s));
+		return AT_OK;
+	}
+	const unsigned ntiles = (unsigned)((npairs + at::SCAN_TILE - 1) / at::SCAN_TILE);
+	int rc = grow(h, &h->d_scan, &h->scan_bytes, (size_t)ntiles * 8);
+	if (rc) return rc;
+	hipLaunchKernelGGL(at::at_scan_tiles, dim3(ntiles), dim3(256), 0, s, d_nops, (long long)npairs, (long long *)h->d_scan);
+	hipLaunchKernelGGL(at::at_scan_nops, dim3(ntiles), dim3(256), 0, s, d_nops, (long long)npairs, (const long long *)h->d_scan,
+	                   (long long *)d_packed_off);
+	{
+		const unsigned grid = (unsigned)std::min<int64_t>((npairs + 15) / 16, 16LL * h->ncu);
+		hipLaunchKernelGGL(at::at_compact_k, dim3(grid), dim3(256), 0, s, (long long)npairs, d_ops, (const long long *)d_ops_off,
+		                   d_nops, d_packed, (const long long *)d_packed_off, (long long)packed_cap);
+	}
+	HIP_TRY(h, hipGetLastError());
+	return AT_OK;
+}
+
 static int align_device(at_handle *h, int mode, int64_t npairs,
                         const uint32_t *d_seq, int bits,
                         const int64_t *d_woff1, const int32_t *d_len1,
@@ -576,11 +640,13 @@ static int align_device(at_handle *h, int mode, int64_t npairs,
 	return AT_OK;
 }
 
-extern "C" int at_align_batch(at_handle *h, int mode, int64_t npairs, const uint8_t *seq_blob,
-                              const int64_t *off1, const int32_t *len1, const int64_t *off2, const int32_t *len2,
-                              int want_traceback,
-                              int32_t *out_score, int32_t *out_end_i, int32_t *out_end_j, int32_t *out_state,
-                              uint8_t *out_ops, const int64_t *ops_off, int32_t *out_nops)
+/* host-buffer entry; with out_r1/out_r2 the strings are rendered on the GPU (slots of len1+len2+1 bytes at ops_off[k])
+ * and the op codes stay on the device */
+static int align_host(at_handle *h, int mode, int64_t npairs, const uint8_t *seq_blob,
+                      const int64_t *off1, const int32_t *len1, const int64_t *off2, const int32_t *len2,
+                      int want_traceback,
+                      int32_t *out_score, int32_t *out_end_i, int32_t *out_end_j, int32_t *out_state,
+                      uint8_t *out_ops, const int64_t *ops_off, int32_t *out_nops, char *out_r1, char *out_r2)
 {
 	if (!h) return fail(nullptr, AT_ERR_ARG, "at_align_batch: NULL handle");
 	if (mode < AT_MODE_GLOBAL || mode > AT_MODE_EDIT) return fail(h, AT_ERR_ARG, "unknown mode %d", mode);
@@ -588,7 +654,8 @@ extern "C" int at_align_batch(at_handle *h, int mode, int64_t npairs, const uint
 	if (npairs == 0) return AT_OK;
 	if (!seq_blob || !off1 || !len1 || !off2 || !len2 || !out_score) return fail(h, AT_ERR_ARG, "NULL argument");
 	const bool tb = want_traceback && mode != AT_MODE_EDIT;
-	if (tb && (!out_ops || !ops_off || !out_nops)) return fail(h, AT_ERR_ARG, "traceback wanted but ops buffers are NULL");
+	const bool strings = out_r1 != nullptr;
+	if (tb && ((!out_ops && !strings) || !ops_off || !out_nops)) return fail(h, AT_ERR_ARG, "traceback wanted but ops buffers are NULL");
 
 	int max1 = 0, max2 = 0;
 	bool uniform = true;
@@ -603,7 +670,7 @@ extern "C" int at_align_batch(at_handle *h, int mode, int64_t npairs, const uint
 		if (mode == AT_MODE_OVERLAP && len2[k] < 1) return fail(h, AT_ERR_DOMAIN, "pair %lld: overlap needs a non-empty second sequence", (long long)k);
 		max1 = std::max(max1, len1[k]); max2 = std::max(max2, len2[k]);
 		if (len1[k] != len1[0] || len2[k] != len2[0]) uniform = false;
-		if (tb) ops_total = std::max<int64_t>(ops_total, ops_off[k] + len1[k] + len2[k]);
+		if (tb) ops_total = std::max<int64_t>(ops_total, ops_off[k] + len1[k] + len2[k] + (strings ? 1 : 0));
 	}
 	HIP_TRY(h, hipSetDevice(h->device));
 
@@ -711,14 +778,50 @@ extern "C" int at_align_batch(at_handle *h, int mode, int64_t npairs, const uint
 	if (out_end_i) HIP_TRY(h, hipMemcpyAsync(out_end_i, d_ei, (size_t)npairs * 4, hipMemcpyDeviceToHost, s));
 	if (out_end_j) HIP_TRY(h, hipMemcpyAsync(out_end_j, d_ej, (size_t)npairs * 4, hipMemcpyDeviceToHost, s));
 	if (out_state) HIP_TRY(h, hipMemcpyAsync(out_state, d_st, (size_t)npairs * 4, hipMemcpyDeviceToHost, s));
+	int rflag = 0;
 	if (tb) {
 		HIP_TRY(h, hipMemcpyAsync(out_nops, d_nops, (size_t)npairs * 4, hipMemcpyDeviceToHost, s));
-		HIP_TRY(h, hipMemcpyAsync(out_ops, d_ops, (size_t)ops_total, hipMemcpyDeviceToHost, s));
+		if (out_ops) HIP_TRY(h, hipMemcpyAsync(out_ops, d_ops, (size_t)ops_total, hipMemcpyDeviceToHost, s));
+		if (strings) {
+			const size_t b_str = al((size_t)ops_total + 64);
+			rc = grow(h, &h->d_str, &h->str_bytes, 2 * b_str);
+			if (rc) return rc;
+			uint8_t *d_r1 = (uint8_t *)h->d_str, *d_r2 = d_r1 + b_str;
+			HIP_TRY(h, hipMemsetAsync(h->d_rflag, 0, 4, s));
+			rc = at_render_batch_device(h, npairs, d_words, bits, d_woff1, d_woff2, d_ei, d_ej, d_ops, d_opsoff, d_nops,
+			                            d_r1, d_r2, nullptr, 1, s);
+			if (rc) return rc;
+			HIP_TRY(h, hipMemcpyAsync(out_r1, d_r1, (size_t)ops_total, hipMemcpyDeviceToHost, s));
+			HIP_TRY(h, hipMemcpyAsync(out_r2, d_r2, (size_t)ops_total, hipMemcpyDeviceToHost, s));
+			HIP_TRY(h, hipMemcpyAsync(&rflag, h->d_rflag, 4, hipMemcpyDeviceToHost, s));
+		}
 	}
 	HIP_TRY(h, hipStreamSynchronize(s));
 	for (int64_t k = 0; k < npairs; ++k) {
 		if (out_score[k] == INT32_MIN || (tb && out_nops[k] < 0))
 			return fail(h, AT_ERR_DOMAIN, "pair %lld: input outside the domain on which the reference is defined", (long long)k);
 	}
+	if (rflag) return fail(h, AT_ERR_DOMAIN, "traceback inconsistent with its sequences");
 	return AT_OK;
+}
+
+extern "C" int at_align_batch(at_handle *h, int mode, int64_t npairs, const uint8_t *seq_blob,
+                              const int64_t *off1, const int32_t *len1, const int64_t *off2, const int32_t *len2,
+                              int want_traceback,
+                              int32_t *out_score, int32_t *out_end_i, int32_t *out_end_j, int32_t *out_state,
+                              uint8_t *out_ops, const int64_t *ops_off, int32_t *out_nops)
+{
+	return align_host(h, mode, npairs, seq_blob, off1, len1, off2, len2, want_traceback, out_score, out_end_i, out_end_j,
+	                  out_state, out_ops, ops_off, out_nops, nullptr, nullptr);
+}
+
+extern "C" int at_align_batch_strings(at_handle *h, int mode, int64_t npairs, const uint8_t *seq_blob,
+                                      const int64_t *off1, const int32_t *len1, const int64_t *off2, const int32_t *len2,
+                                      int32_t *out_score, int32_t *out_end_i, int32_t *out_end_j, int32_t *out_state,
+                                      char *out_r1, char *out_r2, const int64_t *str_off, int32_t *out_len)
+{
+	if (mode == AT_MODE_EDIT) return fail(h, AT_ERR_ARG, "edit has no alignment strings (alignment.h:291)");
+	if (!out_r1 || !out_r2 || !str_off || !out_len) return fail(h, AT_ERR_ARG, "NULL string buffers");
+	return align_host(h, mode, npairs, seq_blob, off1, len1, off2, len2, 1, out_score, out_end_i, out_end_j, out_state,
+	                  nullptr, str_off, out_len, out_r1, out_r2);
 }

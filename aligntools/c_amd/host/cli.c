@@ -119,8 +119,9 @@ static int main_batch(int argc, char *argv[])
 	at_records rec;
 	at_handle *h;
 	size_t n, p, tot = 0;
-	uint8_t *blob, *ops;
-	int64_t *off1, *off2, *opsoff;
+	uint8_t *blob;
+	char *r1, *r2;
+	int64_t *off1, *off2, *stroff;
 	int32_t *l1, *l2, *score, *ei, *ej, *st, *nops;
 	if (argc < 2) { fprintf(stderr, "Usage:   alignTools batch <global|local|fit|overlap|edit> [options] <pairs.fa>\n"); return 1; }
 	for (k = 0; k < 5; ++k) if (strcmp(argv[1], cmd_name[k]) == 0) cmd = k;
@@ -135,8 +136,9 @@ static int main_batch(int argc, char *argv[])
 		opt->sites.size = (size_t)at_parse_sites(rec.comment[1], &opt->sites.pos);
 	}
 	for (p = 0; p < rec.n; ++p) tot += rec.len[p];
-	blob = (uint8_t *)malloc(tot + 1); ops = (uint8_t *)malloc(tot + 64);
-	off1 = (int64_t *)malloc(n * 8); off2 = (int64_t *)malloc(n * 8); opsoff = (int64_t *)malloc(n * 8);
+	blob = (uint8_t *)malloc(tot + 1);
+	r1 = (char *)malloc(tot + n + 64); r2 = (char *)malloc(tot + n + 64);
+	off1 = (int64_t *)malloc(n * 8); off2 = (int64_t *)malloc(n * 8); stroff = (int64_t *)malloc(n * 8);
 	l1 = (int32_t *)malloc(n * 4); l2 = (int32_t *)malloc(n * 4); score = (int32_t *)malloc(n * 4);
 	ei = (int32_t *)malloc(n * 4); ej = (int32_t *)malloc(n * 4); st = (int32_t *)malloc(n * 4); nops = (int32_t *)malloc(n * 4);
 	tot = 0;
@@ -145,24 +147,20 @@ static int main_batch(int argc, char *argv[])
 		memcpy(blob + tot, rec.seq[2 * p], rec.len[2 * p]); tot += rec.len[2 * p];
 		off2[p] = (int64_t)tot; l2[p] = (int32_t)rec.len[2 * p + 1];
 		memcpy(blob + tot, rec.seq[2 * p + 1], rec.len[2 * p + 1]); tot += rec.len[2 * p + 1];
-		opsoff[p] = off1[p];
+		stroff[p] = off1[p] + (int64_t)p;          /* slots of l1+l2+1 bytes */
 		if (cmd == C_FIT && l1[p] > l2[p]) die("first sequence must be shorter than the second\n");
 	}
 	mode = cmd == C_GLOBAL ? AT_MODE_GLOBAL : cmd == C_LOCAL ? AT_MODE_LOCAL : cmd == C_FIT ? AT_MODE_FIT
 	     : cmd == C_OVERLAP ? AT_MODE_OVERLAP : AT_MODE_EDIT;
 	h = at_host_handle();
 	rc = at_set_scoring(h, opt->m, opt->u, opt->o, opt->e, opt->j, opt->s == AT_TRUE, opt->sites.pos, (int)opt->sites.size);
-	if (rc == AT_OK)
-		rc = at_align_batch(h, mode, (int64_t)n, blob, off1, l1, off2, l2, cmd != C_EDIT, score, ei, ej, st, ops, opsoff, nops);
+	if (rc == AT_OK)   /* strings are rendered on the GPU (at_render.hip.h) */
+		rc = cmd == C_EDIT ? at_align_batch(h, mode, (int64_t)n, blob, off1, l1, off2, l2, 0, score, ei, ej, st, NULL, NULL, NULL)
+		                   : at_align_batch_strings(h, mode, (int64_t)n, blob, off1, l1, off2, l2, score, ei, ej, st, r1, r2, stroff, nops);
 	if (rc != AT_OK) die("%s", at_last_error(h));
 	for (p = 0; p < n; ++p) {
 		if (cmd == C_EDIT) { printf("%s\t%s\tedit_distance=%d\n", rec.name[2 * p], rec.name[2 * p + 1], score[p]); continue; }
-		{
-			char *a = (char *)malloc((size_t)nops[p] + 1), *b = (char *)malloc((size_t)nops[p] + 1);
-			at_render(ops + opsoff[p], nops[p], blob + off1[p], ei[p], blob + off2[p], ej[p], a, b);
-			printf("%s\t%s\tscore=%f\n%s\n%s\n", rec.name[2 * p], rec.name[2 * p + 1], (double)score[p], a, b);
-			free(a); free(b);
-		}
+		printf("%s\t%s\tscore=%f\n%s\n%s\n", rec.name[2 * p], rec.name[2 * p + 1], (double)score[p], r1 + stroff[p], r2 + stroff[p]);
 	}
 	return 0;
 }

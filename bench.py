@@ -12,9 +12,11 @@ over the whole batch with the packed inputs already resident in HBM.
 
 Multi-GPU: pairs are independent, so each rank aligns its own 100k-pair shard
 (weak scaling); rank 0 broadcasts the scoring block over RCCL before the timed
-region and every step's fixed-size results (score, end cell, state: 16 B/pair)
-are gathered to all ranks with an asynchronous RCCL all_gather that overlaps the
-next step's kernel.
+region and every step's results are gathered to all ranks over RCCL: the
+fixed-size part (score, end cell, state, CIGAR length: 20 B/pair) with an
+asynchronous all_gather that overlaps the next step's kernel, the CIGARs (ops
+strings) in two phases -- compacted on the GPU, sizes first, then one padded
+payload that travels while the next step computes.
 
 Prints ONE JSON line (rank 0).  `roofline` prices the sweep kernel against the
 HBM roofline with ALGORITHMIC bytes (packed inputs + descriptors read, results +
@@ -75,6 +77,10 @@ def main():
     ap.add_argument("--pairs", type=int, default=0, help="pairs per GPU (default: the workload's)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-traceback", action="store_true")
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
+                    help="process-group backend; gloo only to rehearse the N>1 pipeline with ranks sharing one GPU")
+    ap.add_argument("--render", action="store_true",
+                    help="also turn the op codes into the two gapped strings on the GPU inside every step (at_render_batch_device)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -96,10 +102,14 @@ def main():
     import aligntools.c_amd as A
     from aligntools.c_amd.synth import synth_pairs_blob
 
+    local_rank %= max(1, torch.cuda.device_count())   # (a rehearsal may put several ranks on one card)
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if use_dist:
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        else:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
 
     # ---- scoring block: rank 0 owns it, RCCL broadcast to the other ranks ----
     sc = torch.tensor(list(scoring) + [1 if use_jump else 0, len(sites)] + list(sites) + [0] * (16 - len(sites)),
@@ -132,10 +142,27 @@ def main():
     ops_off = np.arange(pairs, dtype=np.int64) * (l1 + l2)
     d_ops_off = torch.from_numpy(ops_off).to(dev)
     # score, end_i, end_j, state -- two buffers: step k+1 must not overwrite what step k's all_gather still reads
-    d_res2 = [torch.zeros((4, pairs), dtype=torch.int32, device=dev) for _ in range(2)]
-    d_nops = torch.zeros(pairs, dtype=torch.int32, device=dev)
+    # (row 4 = nops, the CIGAR lengths)
+    d_res2 = [torch.zeros((5, pairs), dtype=torch.int32, device=dev) for _ in range(2)]
     d_ops = torch.zeros(pairs * (l1 + l2) + 64, dtype=torch.uint8, device=dev) if tb else None
-    gathered = [torch.empty((world * 4, pairs), dtype=torch.int32, device=dev) for _ in range(2)] if use_dist else None
+    rend = tb and args.render
+    d_r1 = torch.zeros(pairs * (l1 + l2) + 64, dtype=torch.uint8, device=dev) if rend else None
+    d_r2 = torch.zeros(pairs * (l1 + l2) + 64, dtype=torch.uint8, device=dev) if rend else None
+    gathered = [torch.empty((world * 5, pairs), dtype=torch.int32, device=dev) for _ in range(2)] if use_dist else None
+    # CIGAR gather: the ops slots are compacted on the GPU, the per-rank totals are gathered first,
+    # then one payload padded to the largest total.  The payload of step k travels while step k+1 computes.
+    cig = use_dist and tb
+    if cig:
+        cap = pairs * (l1 + l2)
+        d_packed = [torch.zeros(cap + 4096, dtype=torch.uint8, device=dev) for _ in range(2)]
+        d_poff = [torch.zeros(pairs + 1, dtype=torch.int64, device=dev) for _ in range(2)]
+        alltot = [torch.zeros(world, dtype=torch.int64, device=dev) for _ in range(2)]
+        h_tot = [torch.zeros(world, dtype=torch.int64).pin_memory() for _ in range(2)]
+        tot_ev = [torch.cuda.Event() for _ in range(2)]
+        allpay = [None, None]
+        pay_work = [None, None]
+        pay_pad = [0, 0]
+        side = torch.cuda.Stream(device=dev)
 
     def step(k):
         d_res = d_res2[k & 1]
@@ -150,10 +177,44 @@ def main():
                                   d_woff2.data_ptr(), d_len2.data_ptr(), l1, l2, True, tb,
                                   d_res[0].data_ptr(), d_res[1].data_ptr(), d_res[2].data_ptr(), d_res[3].data_ptr(),
                                   d_ops.data_ptr() if tb else None, d_ops_off.data_ptr() if tb else None,
-                                  d_nops.data_ptr() if tb else None, stream)
-        if use_dist:   # gather the fixed-size results of this step; overlaps the next step's kernel
-            return dist.all_gather_into_tensor(gathered[k & 1], d_res, async_op=True)
-        return None
+                                  d_res[4].data_ptr() if tb else None, stream)
+        return d_res
+
+    def finish(k, d_res):
+        if rend:       # ops (END -> START) -> the reference's two strings, in HBM
+            al.render_batch_device(pairs, d_words.data_ptr(), bits, d_woff1.data_ptr(), d_woff2.data_ptr(), d_res[1].data_ptr(),
+                                   d_res[2].data_ptr(), d_ops.data_ptr(), d_ops_off.data_ptr(), d_res[4].data_ptr(),
+                                   d_r1.data_ptr(), d_r2.data_ptr(), None, False, torch.cuda.current_stream().cuda_stream)
+        if not use_dist:
+            return None
+        b = k & 1
+        if cig:
+            if pay_work[b] is not None:   # the payload gather of step k-2 read d_packed[b]
+                pay_work[b].wait()
+            al.compact_ops_device(pairs, d_ops.data_ptr(), d_ops_off.data_ptr(), d_res[4].data_ptr(), d_packed[b].data_ptr(),
+                                  cap, d_poff[b].data_ptr(), torch.cuda.current_stream().cuda_stream)
+        # gather the fixed-size results of this step; overlaps the next step's kernel
+        w = dist.all_gather_into_tensor(gathered[b], d_res, async_op=True)
+        if cig:   # phase 1: every rank's payload size, brought to the host on a side stream
+            wt = dist.all_gather_into_tensor(alltot[b], d_poff[b][pairs:], async_op=True)
+            with torch.cuda.stream(side):
+                wt.wait()
+                h_tot[b].copy_(alltot[b], non_blocking=True)
+                tot_ev[b].record(side)
+        return w
+
+    def payload(k):
+        """Phase 2 of step k's CIGAR gather, issued one step later: by then the sizes are on the host, and the
+        transfer overlaps the sweep kernel of step k+1, which is already queued."""
+        b = k & 1
+        tot_ev[b].synchronize()
+        pad = (max(int(h_tot[b].max()), 1) + 4095) // 4096 * 4096
+        assert pad <= cap + 4096
+        if allpay[b] is None or allpay[b].numel() < world * pad:
+            allpay[b] = torch.empty(world * pad, dtype=torch.uint8, device=dev)
+        pay_pad[b] = pad
+        with torch.cuda.stream(side):
+            pay_work[b] = dist.all_gather_into_tensor(allpay[b][:world * pad], d_packed[b][:pad], async_op=True)
 
     def sync_all():
         torch.cuda.synchronize()
@@ -162,23 +223,34 @@ def main():
         torch.cuda.synchronize()
 
     for k in range(args.warmup):
-        w = step(k)
+        w = finish(k, step(k))
         if w is not None:
             w.wait()
+        if cig:
+            payload(k)
+            pay_work[k & 1].wait()
     sync_all()
     evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
     pending = []
     t0 = time.perf_counter()
     for k in range(args.steps):
         evs[k][0].record()
-        w = step(k)
+        r = step(k)
         evs[k][1].record()
+        if cig and k > 0:
+            payload(k - 1)
+        w = finish(k, r)
         if w is not None:
             pending.append(w)
             if len(pending) > 1:
                 pending.pop(0).wait()
     for w in pending:
         w.wait()
+    if cig and args.steps > 0:
+        payload(args.steps - 1)
+        for w in pay_work:
+            if w is not None:
+                w.wait()
     sync_all()
     t1 = time.perf_counter()
     elapsed = torch.tensor([t1 - t0], dtype=torch.float64, device=dev)
@@ -190,7 +262,21 @@ def main():
     kern_ms = sorted(a.elapsed_time(b) for a, b in evs)
     kern_avg_ms = sum(kern_ms) / len(kern_ms)
     scores = d_res2[(args.steps - 1) & 1][0].cpu().numpy()
-    nops = d_nops.cpu().numpy() if tb else np.zeros(pairs, dtype=np.int32)
+    nops = d_res2[(args.steps - 1) & 1][4].cpu().numpy() if tb else np.zeros(pairs, dtype=np.int32)
+    gather_info = None
+    if cig and args.steps > 0:
+        # what arrived: every rank's total is the sum of its gathered nops, and this rank's part of the payload is its
+        # own ops slots back to back
+        b = (args.steps - 1) & 1
+        g = gathered[b].cpu().numpy().reshape(world, 5, pairs)
+        tots = h_tot[b].numpy()
+        assert (g[:, 4, :].clip(min=0).sum(axis=1) == tots).all(), "CIGAR gather: sizes disagree with the gathered nops"
+        mine = allpay[b][rank * pay_pad[b]: rank * pay_pad[b] + int(tots[rank])].cpu().numpy()
+        slots = d_ops[:pairs * (l1 + l2)].cpu().numpy().reshape(pairs, l1 + l2)
+        assert (mine == slots[np.arange(l1 + l2)[None, :] < nops[:, None]]).all(), "CIGAR gather: payload differs from the ops slots"
+        gather_info = {"fixed_bytes_per_rank": 20 * pairs, "cigar_bytes_per_rank": int(tots[rank]),
+                       "cigar_payload_padded_to": int(pay_pad[b]), "phases": "sizes, then one padded payload; the payload of "
+                       "step k overlaps the sweep of step k+1"}
     assert (scores > -(1 << 30)).all() and (nops >= 0).all(), "kernel reported a domain error"
     cells_per_step = float(pairs) * l1 * l2 * world
     gcups = cells_per_step * args.steps / elapsed / 1e9
@@ -215,7 +301,7 @@ def main():
             "vs_baseline": None, "dtype": "int16" if "packed16" in al.last_config else "int32", "data": "synthetic",
             "config": {"workload": "%s: %s affine-gap, %d x (%dx%d bp) pairs per GPU, uniform ACGT, m=%d u=%d o=%d e=%d%s, "
                                    "%s" % (args.workload, mode, pairs, l1, l2, m, u, o, e, " j=%d -s" % j if uj else "",
-                                           "scores+tracebacks" if tb else "scores only"),
+                                           ("scores+tracebacks+rendered strings" if rend else "scores+tracebacks") if tb else "scores only"),
                        "pairs_per_gpu": pairs, "l1": l1, "l2": l2, "bits_per_base": bits, "kernel_config": al.last_config,
                        "parallelism": "pairs sharded over %d GPU(s), one process per GPU" % world},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
@@ -228,6 +314,8 @@ def main():
                          "valu_gcups_kernel": float(pairs) * l1 * l2 / (kern_avg_ms * 1e-3) / 1e9},
             "cpu_baseline": base,
         }
+        if gather_info:
+            out["config"]["gather"] = gather_info
         print(json.dumps(out))
     if use_dist:
         dist.destroy_process_group()

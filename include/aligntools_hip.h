@@ -130,6 +130,43 @@ int at_align_allpairs_device(at_handle *h, int mode, int64_t nreads,
                              uint8_t *d_ops, const int64_t *d_ops_off, int32_t *d_nops,
                              void *stream);
 
+/*
+ * Output rendering on the GPU: what trace_back_* + strrev produce (alignment.h:372-412,
+ * 558-592, 766-800, 896-922, 172-184) -- the two gapped strings, in reading order -- from the op codes and end
+ * cells at_align_batch_device left in HBM and the same packed sequences.  Pair k's strings are written to
+ * d_r1/d_r2 at byte offset d_str_off[k] (NULL = d_ops_off[k]), d_nops[k] characters each, followed by a 0 byte
+ * when nul_terminate (the slot then needs len1+len2+1 bytes).  Asynchronous on `stream`.
+ */
+int at_render_batch_device(at_handle *h, int64_t npairs,
+                           const uint32_t *d_seq, int bits,
+                           const int64_t *d_woff1, const int64_t *d_woff2,
+                           const int32_t *d_end_i, const int32_t *d_end_j,
+                           const uint8_t *d_ops, const int64_t *d_ops_off, const int32_t *d_nops,
+                           uint8_t *d_r1, uint8_t *d_r2, const int64_t *d_str_off, int nul_terminate,
+                           void *stream);
+
+/*
+ * CIGAR compaction for the result gather (sizes first, then one payload).  Writes the exclusive
+ * prefix sums of d_nops to d_packed_off[0 .. npairs] (d_packed_off[npairs] = total bytes) and copies pair k's ops
+ * from its slot to d_packed[d_packed_off[k] ..).  Pairs that would end beyond packed_cap are not copied: compare the
+ * total with the capacity.  Asynchronous on `stream`.
+ */
+int at_compact_ops_device(at_handle *h, int64_t npairs,
+                          const uint8_t *d_ops, const int64_t *d_ops_off, const int32_t *d_nops,
+                          uint8_t *d_packed, int64_t packed_cap, int64_t *d_packed_off, void *stream);
+
+/*
+ * at_align_batch with the rendering done on the GPU: instead of op codes the caller receives the reference's
+ * two strings per pair (0-terminated) at out_r1/out_r2 + str_off[k], slots of len1[k]+len2[k]+1 bytes, and
+ * their common length in out_len[k].  Not for AT_MODE_EDIT (edit_dist returns a number only).
+ */
+int at_align_batch_strings(at_handle *h, int mode, int64_t npairs,
+                           const uint8_t *seq_blob,
+                           const int64_t *off1, const int32_t *len1,
+                           const int64_t *off2, const int32_t *len2,
+                           int32_t *out_score, int32_t *out_end_i, int32_t *out_end_j, int32_t *out_state,
+                           char *out_r1, char *out_r2, const int64_t *str_off, int32_t *out_len);
+
 /* Host helper: pack `npairs` pairs of raw bytes into the word layout above.
  * bits = 0 picks 2 when every byte is one of ACGT, else 8; the choice is
  * returned in *bits_out.  words_out must hold at_pack_words(...) int32s. */

@@ -50,6 +50,11 @@ def _run_group(al, key, cases):
         else:
             assert len(res["r1"][k]) == c["rlen"]
             assert _md5(res["r1"][k]) == c["r1_md5"] and _md5(res["r2"][k]) == c["r2_md5"], (key, c["tag"])
+    if mode != "edit":
+        # the same strings rendered on the GPU (at_render.hip.h) instead of by at_render on the host
+        gs = al.align_batch_strings(mode, [(c["s1"], c["s2"]) for c in cases])
+        assert gs["r1"] == res["r1"] and gs["r2"] == res["r2"], key
+        assert (gs["score"] == res["score"]).all() and (gs["nops"] == res["nops"]).all()
 
 
 @pytest.mark.parametrize("name", ["random_small.jsonl", "random_dna.jsonl", "known_answers.jsonl"])
@@ -325,3 +330,87 @@ def test_all_vs_all_mode(al):
                 assert got[t] == (ref["score"], ref["end_i"], ref["end_j"], ref["ops"]), (mode, a, b)
                 t += 1
         assert t == total
+
+
+def test_gpu_rendering_device_entry_full_size(al):
+    """at_render_batch_device on the full C2 batch, buffers resident in HBM (the bench.py arrangement): every string
+    equals what at_render makes of the same ops on the host, and r1 / r2 without their gaps are the aligned
+    substrings of s1 / s2."""
+    import torch
+    import aligntools.c_amd as A
+    from aligntools.c_amd.synth import synth_pairs_blob
+    n, l1, l2 = 100000, 150, 150
+    blob = synth_pairs_blob(0x5EED0002, n, l1, l2)
+    # every 5th pair: s2 = mutated s1, so that long alignments with gaps are in the batch
+    rng = random.Random(11)
+    pairs = []
+    for k, row in enumerate(blob):
+        s1 = row[:l1].tobytes()
+        s2 = row[l1:].tobytes()
+        if k % 5 == 0:
+            t = bytearray(s1)
+            for _ in range(6):
+                q = rng.randrange(len(t))
+                r = rng.random()
+                if r < 0.4:
+                    t[q] = rng.choice(b"ACGT")
+                elif r < 0.7:
+                    del t[q]
+                else:
+                    t.insert(q, rng.choice(b"ACGT"))
+            s2 = (bytes(t) + s2)[:l2]
+        pairs.append((s1, s2))
+    dev = torch.device("cuda", 0)
+    words, woff1, woff2, len1, len2, bits = A.pack_pairs(pairs)
+    assert bits == 2
+    t = lambda a: torch.from_numpy(a).to(dev)
+    d_words, d_woff1, d_woff2, d_len1, d_len2 = t(words.view(np.int32)), t(woff1), t(woff2), t(len1), t(len2)
+    d_ops_off = t(np.arange(n, dtype=np.int64) * (l1 + l2))
+    d_str_off = t(np.arange(n, dtype=np.int64) * (l1 + l2 + 1))
+    d_res = torch.zeros((4, n), dtype=torch.int32, device=dev)
+    d_nops = torch.zeros(n, dtype=torch.int32, device=dev)
+    d_ops = torch.zeros(n * (l1 + l2) + 64, dtype=torch.uint8, device=dev)
+    d_r1 = torch.full((n * (l1 + l2 + 1) + 64,), 0x7f, dtype=torch.uint8, device=dev)
+    d_r2 = torch.full((n * (l1 + l2 + 1) + 64,), 0x7f, dtype=torch.uint8, device=dev)
+    al.set_scoring(2, -2, -5, -2)
+    stream = torch.cuda.current_stream().cuda_stream
+    al.align_batch_device(A.MODE_LOCAL, n, d_words.data_ptr(), bits, d_woff1.data_ptr(), d_len1.data_ptr(), d_woff2.data_ptr(),
+                          d_len2.data_ptr(), l1, l2, True, True, d_res[0].data_ptr(), d_res[1].data_ptr(), d_res[2].data_ptr(),
+                          d_res[3].data_ptr(), d_ops.data_ptr(), d_ops_off.data_ptr(), d_nops.data_ptr(), stream)
+    al.render_batch_device(n, d_words.data_ptr(), bits, d_woff1.data_ptr(), d_woff2.data_ptr(), d_res[1].data_ptr(),
+                           d_res[2].data_ptr(), d_ops.data_ptr(), d_ops_off.data_ptr(), d_nops.data_ptr(),
+                           d_r1.data_ptr(), d_r2.data_ptr(), d_str_off.data_ptr(), True, stream)
+    cap = n * 80
+    d_packed = torch.full((cap,), 0x7f, dtype=torch.uint8, device=dev)
+    d_poff = torch.zeros(n + 1, dtype=torch.int64, device=dev)
+    al.compact_ops_device(n, d_ops.data_ptr(), d_ops_off.data_ptr(), d_nops.data_ptr(), d_packed.data_ptr(), cap,
+                          d_poff.data_ptr(), stream)
+    torch.cuda.synchronize()
+    res = d_res.cpu().numpy()
+    nops = d_nops.cpu().numpy()
+    ops = d_ops.cpu().numpy()
+    # CIGAR compaction: offsets are the exclusive scan of nops, the payload is the slots' used parts back to back
+    poff = d_poff.cpu().numpy()
+    want = np.zeros(n + 1, dtype=np.int64)
+    np.cumsum(nops, out=want[1:])
+    assert (poff == want).all() and want[-1] <= cap
+    slots = ops[:n * (l1 + l2)].reshape(n, l1 + l2)
+    mask = np.arange(l1 + l2)[None, :] < nops[:, None]
+    assert (d_packed.cpu().numpy()[:want[-1]] == slots[mask]).all()
+    r1 = d_r1.cpu().numpy().tobytes()
+    r2 = d_r2.cpu().numpy().tobytes()
+    assert nops.max() > 100            # the related pairs align end to end
+    for k in range(n):
+        so, nk = k * (l1 + l2 + 1), int(nops[k])
+        a, b = r1[so:so + nk], r2[so:so + nk]
+        assert r1[so + nk] == 0 and r2[so + nk] == 0
+        ei, ej = int(res[1][k]), int(res[2][k])
+        ga, gb = a.replace(b"-", b""), b.replace(b"-", b"")
+        assert pairs[k][0][ei - len(ga):ei] == ga and pairs[k][1][ej - len(gb):ej] == gb, k
+        if k % 16 == 0:
+            ha, hb = al.render(ops[k * (l1 + l2):k * (l1 + l2) + nk].tobytes(), pairs[k][0], ei, pairs[k][1], ej)
+            assert ha.encode() == a and hb.encode() == b, k
+    for k in rng.sample(range(n), 200):
+        r = O.align(O.LOCAL, pairs[k][0], pairs[k][1], 2, -2, -5, -2)
+        so, nk = k * (l1 + l2 + 1), int(nops[k])
+        assert (r["r1"], r["r2"]) == (r1[so:so + nk].decode(), r2[so:so + nk].decode())

@@ -285,10 +285,15 @@ def main():
     bytes_out = pairs * 16 + (pairs * 4 + int(nops.sum()) if tb else 0)
     achieved = (bytes_in + bytes_out) / (kern_avg_ms * 1e-3) / 1e9
     traffic = None
+    valu_frac = None
     tpath = os.path.join(ROOT, "profiles", "traffic_%s.json" % args.workload)
     if os.path.exists(tpath):
         try:
-            traffic = json.load(open(tpath)).get("hbm_bytes_per_launch")
+            prof = json.load(open(tpath))
+            traffic = prof.get("hbm_bytes_per_launch")
+            # VALU issue bound of the profiled launch (SQ_INSTS_VALU x measured cycles per instruction), live duration
+            if prof.get("valu_issue_bound_ms") and prof.get("valu_issue_bound_pairs") == pairs and tb:
+                valu_frac = prof["valu_issue_bound_ms"] / kern_avg_ms
         except Exception:
             traffic = None
 
@@ -311,7 +316,8 @@ def main():
                          "kernel_min_ms": kern_ms[0], "algorithmic_bytes_per_launch": bytes_in + bytes_out,
                          "note": "integer max/add DP: the binding resource is VALU issue, not HBM (DESIGN.md section 4; "
                                  "profiles/traffic_C2.json holds the SQ counters and the issue-bound model)",
-                         "valu_gcups_kernel": float(pairs) * l1 * l2 / (kern_avg_ms * 1e-3) / 1e9},
+                         "valu_gcups_kernel": float(pairs) * l1 * l2 / (kern_avg_ms * 1e-3) / 1e9,
+                         "valu_issue_frac": valu_frac},
             "cpu_baseline": base,
         }
         if gather_info:

@@ -18,6 +18,13 @@ asynchronous all_gather that overlaps the next step's kernel, the CIGARs (ops
 strings) in two phases -- compacted on the GPU, sizes first, then one padded
 payload that travels while the next step computes.
 
+Steps alternate over `--streams` HIP streams (default 3), each with its own
+handle (workspace, work queue) and output buffers, so up to three launches are
+in flight: the SIMDs that the draining tail of step k leaves idle are taken by
+step k+1 (one launch alone spends 17 % of its time in its first and last round,
+DESIGN.md 3.7).  Every step still computes its whole batch; `--streams 1` runs
+them strictly one after the other.
+
 Prints ONE JSON line (rank 0).  `roofline` prices the sweep kernel against the
 HBM roofline with ALGORITHMIC bytes (packed inputs + descriptors read, results +
 ops written; DESIGN.md section 4) over the HIP-event duration of the launch;
@@ -79,6 +86,9 @@ def main():
     ap.add_argument("--no-traceback", action="store_true")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="process-group backend; gloo only to rehearse the N>1 pipeline with ranks sharing one GPU")
+    ap.add_argument("--streams", type=int, default=3,
+                    help="HIP streams (and handles) the steps alternate over: with 2, the head of step k+1 fills the SIMDs "
+                         "that the draining tail of step k leaves idle")
     ap.add_argument("--render", action="store_true",
                     help="also turn the op codes into the two gapped strings on the GPU inside every step (at_render_batch_device)")
     args = ap.parse_args()
@@ -105,7 +115,12 @@ def main():
     local_rank %= max(1, torch.cuda.device_count())   # (a rehearsal may put several ranks on one card)
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
+    saved_stdout = None
     if use_dist:
+        # RCCL prints a version banner on stdout when its communicator comes up: keep stdout to the one JSON line
+        sys.stdout.flush()
+        saved_stdout = os.dup(1)
+        os.dup2(2, 1)
         if args.backend == "nccl":
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
         else:
@@ -118,10 +133,19 @@ def main():
         if rank != 0:
             sc.zero_()
         dist.broadcast(sc, src=0)
+        torch.cuda.synchronize()
+        sys.stdout.flush()
+        os.dup2(saved_stdout, 1)
+        os.close(saved_stdout)
     scl = sc.cpu().tolist()
     m, u, o, e, j, uj, ns = scl[:7]
-    al = A.Aligner(local_rank)
-    al.set_scoring(m, u, o, e, j, bool(uj), scl[7:7 + ns])
+    S = max(1, args.streams)
+    NB = max(2, S)                                   # buffer sets, used in turn
+    als = [A.Aligner(local_rank) for _ in range(S)]  # one handle (workspace, work queue) per stream
+    for x in als:
+        x.set_scoring(m, u, o, e, j, bool(uj), scl[7:7 + ns])
+    al = als[0]
+    streams = [torch.cuda.Stream(device=dev) for _ in range(S)] if S > 1 else [torch.cuda.current_stream()]
 
     # ---- this rank's shard of the synthetic batch, packed, resident in HBM ----
     allpairs = args.workload == "C5all"
@@ -143,30 +167,35 @@ def main():
     d_ops_off = torch.from_numpy(ops_off).to(dev)
     # score, end_i, end_j, state -- two buffers: step k+1 must not overwrite what step k's all_gather still reads
     # (row 4 = nops, the CIGAR lengths)
-    d_res2 = [torch.zeros((5, pairs), dtype=torch.int32, device=dev) for _ in range(2)]
-    d_ops = torch.zeros(pairs * (l1 + l2) + 64, dtype=torch.uint8, device=dev) if tb else None
+    d_res2 = [torch.zeros((5, pairs), dtype=torch.int32, device=dev) for _ in range(NB)]
+    d_opss = [torch.zeros(pairs * (l1 + l2) + 64, dtype=torch.uint8, device=dev) if tb else None for _ in range(S)]
     rend = tb and args.render
-    d_r1 = torch.zeros(pairs * (l1 + l2) + 64, dtype=torch.uint8, device=dev) if rend else None
-    d_r2 = torch.zeros(pairs * (l1 + l2) + 64, dtype=torch.uint8, device=dev) if rend else None
-    gathered = [torch.empty((world * 5, pairs), dtype=torch.int32, device=dev) for _ in range(2)] if use_dist else None
+    d_r1s = [torch.zeros(pairs * (l1 + l2) + 64, dtype=torch.uint8, device=dev) if rend else None for _ in range(S)]
+    d_r2s = [torch.zeros(pairs * (l1 + l2) + 64, dtype=torch.uint8, device=dev) if rend else None for _ in range(S)]
+    gathered = [torch.empty((world * 5, pairs), dtype=torch.int32, device=dev) for _ in range(NB)] if use_dist else None
+    fixed_work = [None] * NB
     # CIGAR gather: the ops slots are compacted on the GPU, the per-rank totals are gathered first,
     # then one payload padded to the largest total.  The payload of step k travels while step k+1 computes.
     cig = use_dist and tb
     if cig:
         cap = pairs * (l1 + l2)
-        d_packed = [torch.zeros(cap + 4096, dtype=torch.uint8, device=dev) for _ in range(2)]
-        d_poff = [torch.zeros(pairs + 1, dtype=torch.int64, device=dev) for _ in range(2)]
-        alltot = [torch.zeros(world, dtype=torch.int64, device=dev) for _ in range(2)]
-        h_tot = [torch.zeros(world, dtype=torch.int64).pin_memory() for _ in range(2)]
-        tot_ev = [torch.cuda.Event() for _ in range(2)]
-        allpay = [None, None]
-        pay_work = [None, None]
-        pay_pad = [0, 0]
+        d_packed = [torch.zeros(cap + 4096, dtype=torch.uint8, device=dev) for _ in range(NB)]
+        d_poff = [torch.zeros(pairs + 1, dtype=torch.int64, device=dev) for _ in range(NB)]
+        alltot = [torch.zeros(world, dtype=torch.int64, device=dev) for _ in range(NB)]
+        h_tot = [torch.zeros(world, dtype=torch.int64).pin_memory() for _ in range(NB)]
+        tot_ev = [torch.cuda.Event() for _ in range(NB)]
+        allpay = [None] * NB
+        pay_work = [None] * NB
+        pay_pad = [0] * NB
         side = torch.cuda.Stream(device=dev)
 
     def step(k):
-        d_res = d_res2[k & 1]
+        d_res = d_res2[k % NB]
+        al, d_ops = als[k % S], d_opss[k % S]
         stream = torch.cuda.current_stream().cuda_stream
+        if fixed_work[k % NB] is not None:   # the gather of step k-NB still reads this buffer set
+            fixed_work[k % NB].wait()
+            fixed_work[k % NB] = None
         if allpairs:   # this rank's slice of the triangle, a different one every step
             first = ((k * world + rank) * pairs) % (nreads * (nreads - 1) // 2 - pairs)
             al.align_allpairs_device(A.MODES[mode], nreads, d_words.data_ptr(), bits, d_woff1.data_ptr(), d_len1.data_ptr(), l1,
@@ -181,13 +210,14 @@ def main():
         return d_res
 
     def finish(k, d_res):
+        al, d_ops, d_r1, d_r2 = als[k % S], d_opss[k % S], d_r1s[k % S], d_r2s[k % S]
         if rend:       # ops (END -> START) -> the reference's two strings, in HBM
             al.render_batch_device(pairs, d_words.data_ptr(), bits, d_woff1.data_ptr(), d_woff2.data_ptr(), d_res[1].data_ptr(),
                                    d_res[2].data_ptr(), d_ops.data_ptr(), d_ops_off.data_ptr(), d_res[4].data_ptr(),
                                    d_r1.data_ptr(), d_r2.data_ptr(), None, False, torch.cuda.current_stream().cuda_stream)
         if not use_dist:
             return None
-        b = k & 1
+        b = k % NB
         if cig:
             if pay_work[b] is not None:   # the payload gather of step k-2 read d_packed[b]
                 pay_work[b].wait()
@@ -201,12 +231,13 @@ def main():
                 wt.wait()
                 h_tot[b].copy_(alltot[b], non_blocking=True)
                 tot_ev[b].record(side)
+        fixed_work[b] = w
         return w
 
     def payload(k):
         """Phase 2 of step k's CIGAR gather, issued one step later: by then the sizes are on the host, and the
         transfer overlaps the sweep kernel of step k+1, which is already queued."""
-        b = k & 1
+        b = k % NB
         tot_ev[b].synchronize()
         pad = (max(int(h_tot[b].max()), 1) + 4095) // 4096 * 4096
         assert pad <= cap + 4096
@@ -223,29 +254,27 @@ def main():
         torch.cuda.synchronize()
 
     for k in range(args.warmup):
-        w = finish(k, step(k))
-        if w is not None:
-            w.wait()
-        if cig:
-            payload(k)
-            pay_work[k & 1].wait()
+        with torch.cuda.stream(streams[k % S]):
+            w = finish(k, step(k))
+            if w is not None:
+                w.wait()
+            if cig:
+                payload(k)
+                pay_work[k % NB].wait()
     sync_all()
     evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
-    pending = []
     t0 = time.perf_counter()
     for k in range(args.steps):
-        evs[k][0].record()
-        r = step(k)
-        evs[k][1].record()
-        if cig and k > 0:
-            payload(k - 1)
-        w = finish(k, r)
+        with torch.cuda.stream(streams[k % S]):
+            evs[k][0].record()
+            r = step(k)
+            evs[k][1].record()
+            if cig and k > 0:
+                payload(k - 1)
+            finish(k, r)
+    for w in fixed_work:
         if w is not None:
-            pending.append(w)
-            if len(pending) > 1:
-                pending.pop(0).wait()
-    for w in pending:
-        w.wait()
+            w.wait()
     if cig and args.steps > 0:
         payload(args.steps - 1)
         for w in pay_work:
@@ -261,13 +290,28 @@ def main():
     # ---- checks + accounting (outside the timed region) ----
     kern_ms = sorted(a.elapsed_time(b) for a, b in evs)
     kern_avg_ms = sum(kern_ms) / len(kern_ms)
-    scores = d_res2[(args.steps - 1) & 1][0].cpu().numpy()
-    nops = d_res2[(args.steps - 1) & 1][4].cpu().numpy() if tb else np.zeros(pairs, dtype=np.int32)
+    # the same launch with nothing else in flight (what a rocprofv3 trace of `--streams 1` shows)
+    iso = []
+    for k in range(4):
+        ea, eb = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        ea.record()
+        step(args.steps - 1)   # the last step again, into the same buffers
+        eb.record()
+        torch.cuda.synchronize()
+        iso.append(ea.elapsed_time(eb))
+    kern_iso_ms = min(iso)
+    # every buffer set holds the results of the same batch
+    if not allpairs:   # (all-vs-all sweeps a different slice of the triangle every step)
+        for b in range(1, min(NB, args.steps)):
+            assert torch.equal(d_res2[b], d_res2[0]), "buffer sets disagree"
+    d_ops = d_opss[(args.steps - 1) % S]
+    scores = d_res2[(args.steps - 1) % NB][0].cpu().numpy()
+    nops = d_res2[(args.steps - 1) % NB][4].cpu().numpy() if tb else np.zeros(pairs, dtype=np.int32)
     gather_info = None
     if cig and args.steps > 0:
         # what arrived: every rank's total is the sum of its gathered nops, and this rank's part of the payload is its
         # own ops slots back to back
-        b = (args.steps - 1) & 1
+        b = (args.steps - 1) % NB
         g = gathered[b].cpu().numpy().reshape(world, 5, pairs)
         tots = h_tot[b].numpy()
         assert (g[:, 4, :].clip(min=0).sum(axis=1) == tots).all(), "CIGAR gather: sizes disagree with the gathered nops"
@@ -293,7 +337,7 @@ def main():
             traffic = prof.get("hbm_bytes_per_launch")
             # VALU issue bound of the profiled launch (SQ_INSTS_VALU x measured cycles per instruction), live duration
             if prof.get("valu_issue_bound_ms") and prof.get("valu_issue_bound_pairs") == pairs and tb:
-                valu_frac = prof["valu_issue_bound_ms"] / kern_avg_ms
+                valu_frac = prof["valu_issue_bound_ms"] / (elapsed / args.steps * 1e3)
         except Exception:
             traffic = None
 
@@ -308,15 +352,18 @@ def main():
                                    "%s" % (args.workload, mode, pairs, l1, l2, m, u, o, e, " j=%d -s" % j if uj else "",
                                            ("scores+tracebacks+rendered strings" if rend else "scores+tracebacks") if tb else "scores only"),
                        "pairs_per_gpu": pairs, "l1": l1, "l2": l2, "bits_per_base": bits, "kernel_config": al.last_config,
+                       "streams": S,
                        "parallelism": "pairs sharded over %d GPU(s), one process per GPU" % world},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "kernel": ("at_sweep16" if "packed16" in al.last_config else "at_sweep") + "<%s>" % mode,
                          "kernel_avg_ms": kern_avg_ms,
-                         "kernel_min_ms": kern_ms[0], "algorithmic_bytes_per_launch": bytes_in + bytes_out,
+                         "kernel_min_ms": kern_ms[0], "kernel_alone_ms": kern_iso_ms, "launches_in_flight": S,
+                         "achieved_aggregate": (bytes_in + bytes_out) * args.steps / elapsed / 1e9,
+                         "algorithmic_bytes_per_launch": bytes_in + bytes_out,
                          "note": "integer max/add DP: the binding resource is VALU issue, not HBM (DESIGN.md section 4; "
                                  "profiles/traffic_C2.json holds the SQ counters and the issue-bound model)",
-                         "valu_gcups_kernel": float(pairs) * l1 * l2 / (kern_avg_ms * 1e-3) / 1e9,
+                         "valu_gcups_kernel": float(pairs) * l1 * l2 / (kern_iso_ms * 1e-3) / 1e9,
                          "valu_issue_frac": valu_frac},
             "cpu_baseline": base,
         }

@@ -564,10 +564,10 @@ static int align_device(at_handle *h, int mode, int64_t npairs,
 	Layout16 P;
 	if (ts) {
 		P = layout16_for(tb, kmode == at::K_FITJ, max_len1, max_len2, ts);
-		/* A 64-lane packed wave carries 2 alignments where an int32 wave carries 1: fewer, longer work items.  With
-		 * only a round or two of them the coarser granularity costs more than the packing saves (measured on
-		 * 10k x 1024^2: 1.92 vs 2.03 TCUPS; at 61k pairs 2.70 vs 2.19), so small batches stay on the int32 kernel. */
-		const double min_rounds = getenv("AT_PACKED_MIN_ROUNDS") ? atof(getenv("AT_PACKED_MIN_ROUNDS")) : 2.5;
+		/* A 64-lane packed wave carries 2 alignments where an int32 wave carries 1: fewer, longer work items.  A batch
+		 * that cannot give every resident wave one of them stays on the int32 kernel.  (10k x 1024^2 = 1.6 rounds: 1.96
+		 * packed vs 2.00 TCUPS int32 for a lone launch, 2.70 vs 2.13 with launches in flight; 61k pairs: 2.70 vs 2.19.) */
+		const double min_rounds = getenv("AT_PACKED_MIN_ROUNDS") ? atof(getenv("AT_PACKED_MIN_ROUNDS")) : 1.0;
 		if (P.g == 64 && (double)((npairs + 1) / 2) < min_rounds * 12.0 * h->ncu) ts = 0;
 	}
 	if (ts) {

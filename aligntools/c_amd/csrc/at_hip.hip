@@ -225,11 +225,16 @@ struct Layout {
 };
 
 /* rows per lane: enough to hold max_l1 in one strip of 64 lanes, at most 4 */
-static int rows_per_lane(int max_l1)
+static int rows_per_lane(int max_l1, bool deep = false)
 {
 	const long long forced = getenv("AT_ROWS_PER_LANE") ? atoll(getenv("AT_ROWS_PER_LANE")) : 0;
 	if (forced >= 1 && forced <= 4) return (int)forced;
-	return std::max(1, std::min(4, (max_l1 + 63) / 64));
+	const int need = std::max(1, (max_l1 + 63) / 64);
+	/* single-state kernels without a pointer matrix (overlap scores, edit) hold one value per row: 8 or 16 rows per
+	 * lane spread the per-step work (shuffles, end-cell scan, loop) over more cells and fit 1 kbp in one strip */
+	if (deep && need > 4 && !(forced == 8 || forced == 16)) return need <= 8 ? 8 : 16;
+	if (deep && (forced == 8 || forced == 16)) return (int)forced;
+	return std::min(4, need);
 }
 
 static Layout layout_for(int kmode, int bits, bool tb, int max_l1, int max_l2)
@@ -238,7 +243,7 @@ static Layout layout_for(int kmode, int bits, bool tb, int max_l1, int max_l2)
 	const int tbk = (max_l2 + 63 + at::kBlk - 1) / at::kBlk;
 	const int rpb = kmode == at::K_FITJ ? 2 : 1;
 	Layout L;
-	L.k = rows_per_lane(max_l1);
+	L.k = rows_per_lane(max_l1, (kmode == at::K_OVERLAP && !tb) || kmode == at::K_EDIT);
 	L.ptr_lanes = std::max(1, std::min(64, (max_l1 + L.k - 1) / L.k));
 	const long long nstrips = (max_l1 + 64 * L.k - 1) / (64 * L.k);
 	(void)bpw;

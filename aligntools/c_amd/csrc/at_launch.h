@@ -26,6 +26,13 @@ static at_sweep_fn at_pick3(int store, bool tb)
 template <int MODE, int BITS>
 static at_sweep_fn at_pick2(int k, int store, bool tb)
 {
+	if constexpr (MODE == at::K_OVERLAP || MODE == at::K_EDIT) {
+		/* deep lanes for the kernels that keep one value per row and no pointer matrix */
+		if (!tb || MODE == at::K_EDIT) {
+			if (k == 8) return store < 2 ? at::at_sweep<MODE, BITS, 8, true, true, false> : at::at_sweep<MODE, BITS, 8, false, false, false>;
+			if (k == 16) return store < 2 ? at::at_sweep<MODE, BITS, 16, true, true, false> : at::at_sweep<MODE, BITS, 16, false, false, false>;
+		}
+	}
 	switch (k) {
 	case 1: return at_pick3<MODE, BITS, 1>(store, tb);
 	case 2: return at_pick3<MODE, BITS, 2>(store, tb);

@@ -496,9 +496,15 @@ __global__ __launch_bounds__(64) void at_sweep(const SweepArgs a)
 							} else if constexpr (MODE == K_OVERLAP) {
 								/* max5(M(i,j-1)+o, M(i-1,j-1)+s, M(i-1,j)+o): LEFT, DIAGONAL, RIGHT  :944 */
 								const int old = Mo_l[r];
-								const int Mraw = imax3(old | 3, (diag + s16) | 2, up | 1);
-								const int P = (Mraw & ~15) + o16v;
-								nib[r] = (uint32_t)Mraw;
+								int P;
+								if constexpr (TB) {
+									const int Mraw = imax3(old | 3, (diag + s16) | 2, up | 1);
+									P = (Mraw & ~15) + o16v;
+									nib[r] = (uint32_t)Mraw;
+								} else {
+									/* scores only: the priority tags decide pointers, never values */
+									P = imax3(old, diag + s16, up) + o16v;
+								}
 								Mo_l[r] = P; diag = old; up = P;
 							} else {
 								/* min3(D(i,j-1)+1, D(i-1,j-1)+cost, D(i-1,j)+1)  :306-309 */

@@ -289,6 +289,46 @@ def test_score_only_batches(al):
                     assert (int(res["end_i"][k]), int(res["end_j"][k]), int(res["state"][k])) == (r["end_i"], r["end_j"], r["state"])
 
 
+def test_deep_lane_kernels_overlap_scores_and_edit(al):
+    """Overlap without tracebacks and edit run with 8 or 16 rows per lane once the first sequence is longer than 256:
+    one strip (257..1024 rows), several strips (> 1024), ragged batches, row l1 anywhere inside its lane, both alphabets."""
+    rng = random.Random(21)
+    dna = lambda n: "".join(rng.choice("ACGT") for _ in range(n))
+    prot = lambda n: "".join(rng.choice("ACDEFGHIKL") for _ in range(n))
+    def related(a, gen):
+        t = list(a)
+        for _ in range(max(1, len(t) // 25)):
+            q = rng.randrange(len(t))
+            r = rng.random()
+            if r < 0.4:
+                t[q] = gen(1)
+            elif r < 0.7:
+                del t[q]
+            else:
+                t.insert(q, gen(1))
+        return "".join(t)
+    batches = []
+    for gen in (dna, prot):
+        lens = [257, 300, 511, 512, 513, 640, 999, 1000, 1001, 1023, 1024, 1025, 1500, 2049]
+        pairs = []
+        for n in lens:
+            a = gen(n)
+            pairs.append((a, gen(rng.randint(200, 1100))))
+            pairs.append((a, related(a[n // 3:], gen) + gen(50)))      # a suffix of s1 opens s2: a real overlap
+        batches.append(pairs)
+        batches.append([(gen(1000), gen(1000)) for _ in range(9)])     # uniform 1 kbp reads (the C5 shape)
+    for pairs in batches:
+        for mode, sc in (("overlap", (1, -2, -5, -1)), ("overlap", (2, -3, -4, -1)), ("edit", (1, 1, -5, -1)), ("edit", (1, -2, -5, -1))):
+            al.set_scoring(*sc)
+            res = al.align_batch(mode, pairs, traceback=False)
+            assert "rows/lane=8" in al.last_config or "rows/lane=16" in al.last_config, al.last_config
+            for k, (a, b) in enumerate(pairs):
+                r = O.align(O.MODE_NAMES[mode], a, b, *sc)
+                assert int(res["score"][k]) == r["score"], (mode, sc, k, len(a), len(b))
+                if mode == "overlap":
+                    assert (int(res["end_i"][k]), int(res["end_j"][k])) == (r["end_i"], r["end_j"]), (mode, sc, k, len(a), len(b))
+
+
 def test_all_vs_all_mode(al):
     """BASELINE config 'overlap all-vs-all': ordered pairs (a < b) enumerated on the GPU from a linear triangle
     index (no per-pair descriptors), split in two ranges like two ranks would; every pair equals the oracle."""

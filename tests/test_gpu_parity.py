@@ -454,3 +454,16 @@ def test_gpu_rendering_device_entry_full_size(al):
         r = O.align(O.LOCAL, pairs[k][0], pairs[k][1], 2, -2, -5, -2)
         so, nk = k * (l1 + l2 + 1), int(nops[k])
         assert (r["r1"], r["r2"]) == (r1[so:so + nk].decode(), r2[so:so + nk].decode())
+    # d_str_off = NULL: the strings go to the ops offsets, without terminators (what bench.py --render does)
+    d_r1.fill_(0x7f)
+    d_r2.fill_(0x7f)
+    al.render_batch_device(n, d_words.data_ptr(), bits, d_woff1.data_ptr(), d_woff2.data_ptr(), d_res[1].data_ptr(),
+                           d_res[2].data_ptr(), d_ops.data_ptr(), d_ops_off.data_ptr(), d_nops.data_ptr(),
+                           d_r1.data_ptr(), d_r2.data_ptr(), None, False, stream)
+    torch.cuda.synchronize()
+    q1 = d_r1.cpu().numpy().tobytes()
+    q2 = d_r2.cpu().numpy().tobytes()
+    for k in range(0, n, 3):
+        so, oo, nk = k * (l1 + l2 + 1), k * (l1 + l2), int(nops[k])
+        assert q1[oo:oo + nk] == r1[so:so + nk] and q2[oo:oo + nk] == r2[so:so + nk]
+        assert nk == l1 + l2 or q1[oo + nk] == 0x7f           # nothing written behind the string

@@ -16,6 +16,7 @@
 #include <cstring>
 #include <functional>
 #include <string>
+#include <thread>
 #include <vector>
 
 using at::SweepArgs;
@@ -40,6 +41,7 @@ struct at_handle {
 	void *d_str = nullptr; size_t str_bytes = 0;
 	void *d_scan = nullptr; size_t scan_bytes = 0;
 	int *d_rflag = nullptr;         /* at_render_k's "op list walks off its sequences" flag */
+	std::vector<at_handle *> kids;  /* helper handles of the host entry: chunks of one batch in flight side by side */
 	char err[512] = {0};
 	char cfg[320] = "none";
 };
@@ -101,6 +103,8 @@ extern "C" int at_init(const int *device_ids, int n_devices, at_handle **out)
 extern "C" void at_destroy(at_handle *h)
 {
 	if (!h) return;
+	for (at_handle *k : h->kids) at_destroy(k);
+	h->kids.clear();
 	(void)hipSetDevice(h->device);
 	if (h->d_sitemask) (void)hipFree(h->d_sitemask);
 	if (h->d_ws) (void)hipFree(h->d_ws);
@@ -664,7 +668,7 @@ static int align_host(at_handle *h, int mode, int64_t npairs, const uint8_t *seq
 
 	int max1 = 0, max2 = 0;
 	bool uniform = true;
-	int64_t ops_total = 0;
+	int64_t ops_total = 0, ops_lo = INT64_MAX, blob_lo = INT64_MAX;
 	for (int64_t k = 0; k < npairs; ++k) {
 		if (len1[k] < 0 || len2[k] < 0) return fail(h, AT_ERR_ARG, "pair %lld: negative length", (long long)k);
 		/* the domain on which the reference is defined (last paragraph) */
@@ -675,8 +679,18 @@ static int align_host(at_handle *h, int mode, int64_t npairs, const uint8_t *seq
 		if (mode == AT_MODE_OVERLAP && len2[k] < 1) return fail(h, AT_ERR_DOMAIN, "pair %lld: overlap needs a non-empty second sequence", (long long)k);
 		max1 = std::max(max1, len1[k]); max2 = std::max(max2, len2[k]);
 		if (len1[k] != len1[0] || len2[k] != len2[0]) uniform = false;
-		if (tb) ops_total = std::max<int64_t>(ops_total, ops_off[k] + len1[k] + len2[k] + (strings ? 1 : 0));
+		if (tb) {
+			if (ops_off[k] < 0) return fail(h, AT_ERR_ARG, "pair %lld: negative ops offset", (long long)k);
+			ops_total = std::max<int64_t>(ops_total, ops_off[k] + len1[k] + len2[k] + (strings ? 1 : 0));
+			ops_lo = std::min<int64_t>(ops_lo, ops_off[k]);
+		}
+		if (off1[k] < 0 || off2[k] < 0) return fail(h, AT_ERR_ARG, "pair %lld: negative sequence offset", (long long)k);
+		blob_lo = std::min<int64_t>(blob_lo, std::min(off1[k], off2[k]));
 	}
+	/* only the span of the blob and of the ops buffer that this call touches travels (a chunk of a larger batch,
+	 * see at_align_batch, addresses the caller's buffers with absolute offsets) */
+	if (!tb) ops_lo = 0;
+	ops_total -= ops_lo;
 	HIP_TRY(h, hipSetDevice(h->device));
 
 	/* ---- inputs go up RAW; packing happens on the GPU (at_pack.hip.h).  Host work is O(npairs): word offsets. ---- */
@@ -684,8 +698,8 @@ static int align_host(at_handle *h, int mode, int64_t npairs, const uint8_t *seq
 	std::vector<int32_t> slen((size_t)2 * npairs);
 	int64_t nwords2 = 0, nwords8 = 0, blob_bytes = 0;
 	for (int64_t k = 0; k < npairs; ++k) {
-		soff[2 * k] = off1[k]; slen[2 * k] = len1[k];
-		soff[2 * k + 1] = off2[k]; slen[2 * k + 1] = len2[k];
+		soff[2 * k] = off1[k] - blob_lo; slen[2 * k] = len1[k];
+		soff[2 * k + 1] = off2[k] - blob_lo; slen[2 * k + 1] = len2[k];
 		for (int q = 0; q < 2; ++q) {
 			const int len = slen[2 * k + q];
 			swoff2[2 * k + q] = nwords2; nwords2 += (len + 15) / 16 + 1;
@@ -710,10 +724,15 @@ static int align_host(at_handle *h, int mode, int64_t npairs, const uint8_t *seq
 	int *d_flag = (int *)(din + b_words + 3 * b_off + b_len);
 	uint8_t *d_blob = (uint8_t *)(din + b_words + 3 * b_off + b_len + 256);
 	hipStream_t s = h->stream;
-	HIP_TRY(h, hipMemcpyAsync(d_blob, seq_blob, (size_t)blob_bytes, hipMemcpyHostToDevice, s));
+	HIP_TRY(h, hipMemcpyAsync(d_blob, seq_blob + blob_lo, (size_t)blob_bytes, hipMemcpyHostToDevice, s));
 	HIP_TRY(h, hipMemcpyAsync(d_soff, soff.data(), (size_t)2 * npairs * 8, hipMemcpyHostToDevice, s));
 	HIP_TRY(h, hipMemcpyAsync(d_slen, slen.data(), (size_t)2 * npairs * 4, hipMemcpyHostToDevice, s));
-	if (tb) HIP_TRY(h, hipMemcpyAsync(d_opsoff, ops_off, (size_t)npairs * 8, hipMemcpyHostToDevice, s));
+	std::vector<int64_t> opsr;
+	if (tb) {
+		opsr.resize((size_t)npairs);
+		for (int64_t k = 0; k < npairs; ++k) opsr[(size_t)k] = ops_off[k] - ops_lo;
+		HIP_TRY(h, hipMemcpyAsync(d_opsoff, opsr.data(), (size_t)npairs * 8, hipMemcpyHostToDevice, s));
+	}
 	at::PackArgs pa;
 	pa.nseq = 2 * npairs; pa.blob = d_blob; pa.off = (const long long *)d_soff; pa.len = d_slen;
 	pa.woff = (const long long *)d_swoff; pa.words = d_words; pa.not_acgt = d_flag;
@@ -786,7 +805,7 @@ static int align_host(at_handle *h, int mode, int64_t npairs, const uint8_t *seq
 	int rflag = 0;
 	if (tb) {
 		HIP_TRY(h, hipMemcpyAsync(out_nops, d_nops, (size_t)npairs * 4, hipMemcpyDeviceToHost, s));
-		if (out_ops) HIP_TRY(h, hipMemcpyAsync(out_ops, d_ops, (size_t)ops_total, hipMemcpyDeviceToHost, s));
+		if (out_ops) HIP_TRY(h, hipMemcpyAsync(out_ops + ops_lo, d_ops, (size_t)ops_total, hipMemcpyDeviceToHost, s));
 		if (strings) {
 			const size_t b_str = al((size_t)ops_total + 64);
 			rc = grow(h, &h->d_str, &h->str_bytes, 2 * b_str);
@@ -796,8 +815,8 @@ static int align_host(at_handle *h, int mode, int64_t npairs, const uint8_t *seq
 			rc = at_render_batch_device(h, npairs, d_words, bits, d_woff1, d_woff2, d_ei, d_ej, d_ops, d_opsoff, d_nops,
 			                            d_r1, d_r2, nullptr, 1, s);
 			if (rc) return rc;
-			HIP_TRY(h, hipMemcpyAsync(out_r1, d_r1, (size_t)ops_total, hipMemcpyDeviceToHost, s));
-			HIP_TRY(h, hipMemcpyAsync(out_r2, d_r2, (size_t)ops_total, hipMemcpyDeviceToHost, s));
+			HIP_TRY(h, hipMemcpyAsync(out_r1 + ops_lo, d_r1, (size_t)ops_total, hipMemcpyDeviceToHost, s));
+			HIP_TRY(h, hipMemcpyAsync(out_r2 + ops_lo, d_r2, (size_t)ops_total, hipMemcpyDeviceToHost, s));
 			HIP_TRY(h, hipMemcpyAsync(&rflag, h->d_rflag, 4, hipMemcpyDeviceToHost, s));
 		}
 	}
@@ -810,14 +829,71 @@ static int align_host(at_handle *h, int mode, int64_t npairs, const uint8_t *seq
 	return AT_OK;
 }
 
+/* A large batch is cut into contiguous chunks that run side by side, each on its own handle (stream, workspace) and
+ * host thread: the upload of one chunk, the sweep of another and the download of a third overlap, and the launches fill
+ * each other's tails.  Chunks address the caller's buffers with the caller's absolute offsets. */
+static int align_host_mt(at_handle *h, int mode, int64_t npairs, const uint8_t *seq_blob,
+                         const int64_t *off1, const int32_t *len1, const int64_t *off2, const int32_t *len2,
+                         int want_traceback,
+                         int32_t *out_score, int32_t *out_end_i, int32_t *out_end_j, int32_t *out_state,
+                         uint8_t *out_ops, const int64_t *ops_off, int32_t *out_nops, char *out_r1, char *out_r2)
+{
+	const long long want = env_ll("AT_HOST_CHUNKS", 3);
+	const long long min_pairs = env_ll("AT_HOST_CHUNK_MIN", 16384);
+	int nchunks = (int)std::max<long long>(1, std::min<long long>(want, 8));
+	if (!h || npairs < 2 * min_pairs || !seq_blob || !off1 || !len1 || !off2 || !len2 || !out_score) nchunks = 1;
+	else nchunks = (int)std::min<long long>(nchunks, npairs / min_pairs);
+	if (nchunks <= 1)
+		return align_host(h, mode, npairs, seq_blob, off1, len1, off2, len2, want_traceback, out_score, out_end_i, out_end_j,
+		                  out_state, out_ops, ops_off, out_nops, out_r1, out_r2);
+	while ((int)h->kids.size() < nchunks - 1) {
+		at_handle *k = nullptr;
+		const int dev = h->device;
+		const int rc = at_init(&dev, 1, &k);
+		if (rc) return fail(h, rc, "helper handle: %s", at_last_error(nullptr));
+		h->kids.push_back(k);
+	}
+	for (int c = 0; c < nchunks - 1; ++c) {
+		at_handle *k = h->kids[(size_t)c];
+		if (k->m != h->m || k->u != h->u || k->o != h->o || k->e != h->e || k->j != h->j || k->use_jump != h->use_jump ||
+		    k->sites != h->sites) {
+			k->m = h->m; k->u = h->u; k->o = h->o; k->e = h->e; k->j = h->j; k->use_jump = h->use_jump; k->sites = h->sites;
+			k->sitemask_dirty = true;
+		}
+	}
+	std::vector<int> rcs((size_t)nchunks, AT_OK);
+	std::vector<std::thread> th;
+	const int64_t per = ((npairs + nchunks - 1) / nchunks + 7) & ~(int64_t)7;
+	auto run = [&](int c) {
+		const int64_t lo = std::min<int64_t>(npairs, c * per), n = std::min<int64_t>(npairs, lo + per) - lo;
+		at_handle *hh = c == 0 ? h : h->kids[(size_t)c - 1];
+		if (n <= 0) return;
+		rcs[(size_t)c] = align_host(hh, mode, n, seq_blob, off1 + lo, len1 + lo, off2 + lo, len2 + lo, want_traceback,
+		                            out_score + lo, out_end_i ? out_end_i + lo : nullptr, out_end_j ? out_end_j + lo : nullptr,
+		                            out_state ? out_state + lo : nullptr, out_ops, ops_off ? ops_off + lo : nullptr,
+		                            out_nops ? out_nops + lo : nullptr, out_r1, out_r2);
+	};
+	for (int c = 1; c < nchunks; ++c) th.emplace_back(run, c);
+	run(0);
+	for (auto &t : th) t.join();
+	for (int c = 0; c < nchunks; ++c) {
+		if (rcs[(size_t)c] != AT_OK) {
+			if (c > 0) snprintf(h->err, sizeof h->err, "%s", h->kids[(size_t)c - 1]->err);
+			return rcs[(size_t)c];
+		}
+	}
+	snprintf(h->cfg + strlen(h->cfg), sizeof h->cfg - strlen(h->cfg), " x%d chunks", nchunks);
+	return AT_OK;
+}
+
 extern "C" int at_align_batch(at_handle *h, int mode, int64_t npairs, const uint8_t *seq_blob,
                               const int64_t *off1, const int32_t *len1, const int64_t *off2, const int32_t *len2,
                               int want_traceback,
                               int32_t *out_score, int32_t *out_end_i, int32_t *out_end_j, int32_t *out_state,
                               uint8_t *out_ops, const int64_t *ops_off, int32_t *out_nops)
 {
-	return align_host(h, mode, npairs, seq_blob, off1, len1, off2, len2, want_traceback, out_score, out_end_i, out_end_j,
-	                  out_state, out_ops, ops_off, out_nops, nullptr, nullptr);
+	return align_host_mt(h, mode, npairs, seq_blob, off1, len1, off2, len2, want_traceback, out_score, out_end_i, out_end_j,
+	                     out_state, out_ops, ops_off, out_nops, nullptr, nullptr);
 }
 
 extern "C" int at_align_batch_strings(at_handle *h, int mode, int64_t npairs, const uint8_t *seq_blob,
@@ -827,6 +903,6 @@ extern "C" int at_align_batch_strings(at_handle *h, int mode, int64_t npairs, co
 {
 	if (mode == AT_MODE_EDIT) return fail(h, AT_ERR_ARG, "edit has no alignment strings (alignment.h:291)");
 	if (!out_r1 || !out_r2 || !str_off || !out_len) return fail(h, AT_ERR_ARG, "NULL string buffers");
-	return align_host(h, mode, npairs, seq_blob, off1, len1, off2, len2, 1, out_score, out_end_i, out_end_j, out_state,
-	                  nullptr, str_off, out_len, out_r1, out_r2);
+	return align_host_mt(h, mode, npairs, seq_blob, off1, len1, off2, len2, 1, out_score, out_end_i, out_end_j, out_state,
+	                     nullptr, str_off, out_len, out_r1, out_r2);
 }

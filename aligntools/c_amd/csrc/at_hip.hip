@@ -655,7 +655,8 @@ static int align_host(at_handle *h, int mode, int64_t npairs, const uint8_t *seq
                       const int64_t *off1, const int32_t *len1, const int64_t *off2, const int32_t *len2,
                       int want_traceback,
                       int32_t *out_score, int32_t *out_end_i, int32_t *out_end_j, int32_t *out_state,
-                      uint8_t *out_ops, const int64_t *ops_off, int32_t *out_nops, char *out_r1, char *out_r2)
+                      uint8_t *out_ops, const int64_t *ops_off, int32_t *out_nops, char *out_r1, char *out_r2,
+                      int64_t pair_base = 0)   /* index of pair 0 in the caller's batch, for messages */
 {
 	if (!h) return fail(nullptr, AT_ERR_ARG, "at_align_batch: NULL handle");
 	if (mode < AT_MODE_GLOBAL || mode > AT_MODE_EDIT) return fail(h, AT_ERR_ARG, "unknown mode %d", mode);
@@ -670,21 +671,21 @@ static int align_host(at_handle *h, int mode, int64_t npairs, const uint8_t *seq
 	bool uniform = true;
 	int64_t ops_total = 0, ops_lo = INT64_MAX, blob_lo = INT64_MAX;
 	for (int64_t k = 0; k < npairs; ++k) {
-		if (len1[k] < 0 || len2[k] < 0) return fail(h, AT_ERR_ARG, "pair %lld: negative length", (long long)k);
+		if (len1[k] < 0 || len2[k] < 0) return fail(h, AT_ERR_ARG, "pair %lld: negative length", (long long)(pair_base + k));
 		/* the domain on which the reference is defined (last paragraph) */
 		if (mode == AT_MODE_FIT && len1[k] > len2[k])
 			return fail(h, AT_ERR_FIT_ORDER, "first sequence must be shorter than the second");
-		if (mode == AT_MODE_LOCAL && (len1[k] < 1 || len2[k] < 1)) return fail(h, AT_ERR_DOMAIN, "pair %lld: local needs non-empty sequences", (long long)k);
-		if (mode == AT_MODE_FIT && len1[k] < 1) return fail(h, AT_ERR_DOMAIN, "pair %lld: fit needs a non-empty read", (long long)k);
-		if (mode == AT_MODE_OVERLAP && len2[k] < 1) return fail(h, AT_ERR_DOMAIN, "pair %lld: overlap needs a non-empty second sequence", (long long)k);
+		if (mode == AT_MODE_LOCAL && (len1[k] < 1 || len2[k] < 1)) return fail(h, AT_ERR_DOMAIN, "pair %lld: local needs non-empty sequences", (long long)(pair_base + k));
+		if (mode == AT_MODE_FIT && len1[k] < 1) return fail(h, AT_ERR_DOMAIN, "pair %lld: fit needs a non-empty read", (long long)(pair_base + k));
+		if (mode == AT_MODE_OVERLAP && len2[k] < 1) return fail(h, AT_ERR_DOMAIN, "pair %lld: overlap needs a non-empty second sequence", (long long)(pair_base + k));
 		max1 = std::max(max1, len1[k]); max2 = std::max(max2, len2[k]);
 		if (len1[k] != len1[0] || len2[k] != len2[0]) uniform = false;
 		if (tb) {
-			if (ops_off[k] < 0) return fail(h, AT_ERR_ARG, "pair %lld: negative ops offset", (long long)k);
+			if (ops_off[k] < 0) return fail(h, AT_ERR_ARG, "pair %lld: negative ops offset", (long long)(pair_base + k));
 			ops_total = std::max<int64_t>(ops_total, ops_off[k] + len1[k] + len2[k] + (strings ? 1 : 0));
 			ops_lo = std::min<int64_t>(ops_lo, ops_off[k]);
 		}
-		if (off1[k] < 0 || off2[k] < 0) return fail(h, AT_ERR_ARG, "pair %lld: negative sequence offset", (long long)k);
+		if (off1[k] < 0 || off2[k] < 0) return fail(h, AT_ERR_ARG, "pair %lld: negative sequence offset", (long long)(pair_base + k));
 		blob_lo = std::min<int64_t>(blob_lo, std::min(off1[k], off2[k]));
 	}
 	/* only the span of the blob and of the ops buffer that this call touches travels (a chunk of a larger batch,
@@ -823,7 +824,7 @@ static int align_host(at_handle *h, int mode, int64_t npairs, const uint8_t *seq
 	HIP_TRY(h, hipStreamSynchronize(s));
 	for (int64_t k = 0; k < npairs; ++k) {
 		if (out_score[k] == INT32_MIN || (tb && out_nops[k] < 0))
-			return fail(h, AT_ERR_DOMAIN, "pair %lld: input outside the domain on which the reference is defined", (long long)k);
+			return fail(h, AT_ERR_DOMAIN, "pair %lld: input outside the domain on which the reference is defined", (long long)(pair_base + k));
 	}
 	if (rflag) return fail(h, AT_ERR_DOMAIN, "traceback inconsistent with its sequences");
 	return AT_OK;
@@ -871,7 +872,7 @@ static int align_host_mt(at_handle *h, int mode, int64_t npairs, const uint8_t *
 		rcs[(size_t)c] = align_host(hh, mode, n, seq_blob, off1 + lo, len1 + lo, off2 + lo, len2 + lo, want_traceback,
 		                            out_score + lo, out_end_i ? out_end_i + lo : nullptr, out_end_j ? out_end_j + lo : nullptr,
 		                            out_state ? out_state + lo : nullptr, out_ops, ops_off ? ops_off + lo : nullptr,
-		                            out_nops ? out_nops + lo : nullptr, out_r1, out_r2);
+		                            out_nops ? out_nops + lo : nullptr, out_r1, out_r2, lo);
 	};
 	for (int c = 1; c < nchunks; ++c) th.emplace_back(run, c);
 	run(0);

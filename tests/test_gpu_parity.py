@@ -329,6 +329,39 @@ def test_deep_lane_kernels_overlap_scores_and_edit(al):
                     assert (int(res["end_i"][k]), int(res["end_j"][k])) == (r["end_i"], r["end_j"]), (mode, sc, k, len(a), len(b))
 
 
+def test_chunked_host_entry(al):
+    """Batches of >= 32k pairs go through the host entry as chunks on helper handles and threads: the results equal
+    the one-piece run (AT_HOST_CHUNKS=1), ragged shapes included, and an error names the pair by its batch index."""
+    import os
+    import aligntools.c_amd as A
+    rng = random.Random(33)
+    n = 40000
+    pairs = [("".join(rng.choice("ACGT") for _ in range(rng.randint(20, 60))), "".join(rng.choice("ACGT") for _ in range(rng.randint(60, 90))))
+             for _ in range(n)]
+    al.set_scoring(2, -2, -5, -2)
+    for mode in ("local", "fit"):
+        chunked = al.align_batch(mode, pairs, render=False)
+        assert "chunks" in al.last_config
+        os.environ["AT_HOST_CHUNKS"] = "1"
+        try:
+            whole = al.align_batch(mode, pairs, render=False)
+            assert "chunks" not in al.last_config
+        finally:
+            del os.environ["AT_HOST_CHUNKS"]
+        for key in ("score", "end_i", "end_j", "state", "nops"):
+            assert (chunked[key] == whole[key]).all(), (mode, key)
+        assert chunked["ops"] == whole["ops"]
+        gs = al.align_batch_strings(mode, pairs[:33000])
+        for k in rng.sample(range(33000), 200):
+            r = O.align(O.MODE_NAMES[mode], pairs[k][0], pairs[k][1], 2, -2, -5, -2)
+            assert (int(gs["score"][k]), gs["r1"][k], gs["r2"][k]) == (r["score"], r["r1"], r["r2"]), (mode, k)
+    bad = list(pairs)
+    bad[39999] = ("", "ACGT")
+    with pytest.raises(A.AlignToolsError) as ei:
+        al.align_batch("local", bad)
+    assert ei.value.code == -4 and "39999" in str(ei.value)
+
+
 def test_all_vs_all_mode(al):
     """BASELINE config 'overlap all-vs-all': ordered pairs (a < b) enumerated on the GPU from a linear triangle
     index (no per-pair descriptors), split in two ranges like two ranks would; every pair equals the oracle."""

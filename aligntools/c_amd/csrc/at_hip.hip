@@ -46,7 +46,7 @@ struct at_handle {
 	char cfg[320] = "none";
 };
 
-static char g_err[512] = "no error";
+static thread_local char g_err[512] = "no error";   /* per thread: the host entry runs chunks on helper threads */
 
 static int fail(at_handle *h, int code, const char *fmt, ...)
 {
@@ -880,6 +880,7 @@ static int align_host_mt(at_handle *h, int mode, int64_t npairs, const uint8_t *
 	for (int c = 0; c < nchunks; ++c) {
 		if (rcs[(size_t)c] != AT_OK) {
 			if (c > 0) snprintf(h->err, sizeof h->err, "%s", h->kids[(size_t)c - 1]->err);
+			snprintf(g_err, sizeof g_err, "%s", h->err);
 			return rcs[(size_t)c];
 		}
 	}

@@ -56,6 +56,7 @@ typedef struct at_handle at_handle;
  * device_ids == NULL selects the current device. */
 int at_init(const int *device_ids, int n_devices, at_handle **out);
 void at_destroy(at_handle *h);
+/* Text of the last error on handle h; h == NULL: of the calling thread's last failure without a handle (at_init). */
 const char *at_last_error(const at_handle *h);
 
 /* Scoring block = the reference's opt_t (alignment.h:57-65, defaults :102-114:

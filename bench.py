@@ -6,7 +6,7 @@ gap, 100k synthetic 150x150 bp pairs, scores AND tracebacks (ops strings),
 m=2 u=-2 o=-5 e=-2.  A "step" is one pass of the hot path
 over the whole batch with the packed inputs already resident in HBM.
 
-    python bench.py --gpus 1 --steps 20 --warmup 3
+    python bench.py --gpus 1 --steps 200 --warmup 5
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
         --master-port P bench.py --gpus N --steps K --warmup W
 
@@ -78,8 +78,8 @@ def cpu_baseline(mode, l1, l2, scoring, use_jump, sites, seed, target_s=15.0):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--workload", default="C2", choices=sorted(WORKLOADS))
     ap.add_argument("--pairs", type=int, default=0, help="pairs per GPU (default: the workload's)")
     ap.add_argument("--no-cpu-baseline", action="store_true")

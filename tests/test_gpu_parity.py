@@ -329,6 +329,37 @@ def test_deep_lane_kernels_overlap_scores_and_edit(al):
                     assert (int(res["end_i"][k]), int(res["end_j"][k])) == (r["end_i"], r["end_j"]), (mode, sc, k, len(a), len(b))
 
 
+@pytest.mark.parametrize("cfg", ["C3", "C4", "C5"])
+def test_baseline_shapes_at_scale(al, cfg):
+    """BASELINE configs[2..4] at sizes that fill the chip for several rounds of the work queue (pointer slots reused,
+    launches of the host entry in flight side by side): a seeded sample of every batch equals the oracle bit for bit --
+    half of the pairs unrelated, half related (long tracebacks with gaps)."""
+    from aligntools.c_amd.synth import synth_pairs_blob, mutate_pairs
+    mode, l1, l2, n, sc, uj, sites, nsample = {
+        "C3": ("global", 1024, 1024, 4000, (1, -1, -4, -1, -10), False, [], 12),
+        "C4": ("fit", 150, 500, 40000, (2, -2, -5, -1, -10), True, [100, 200, 300, 400], 150),
+        "C5": ("overlap", 1000, 1000, 3000, (1, -2, -5, -1, -10), False, [], 12),
+    }[cfg]
+    blob = synth_pairs_blob(0x5EED0100 + len(cfg) + ord(cfg[1]), n, l1, l2)
+    rel = mutate_pairs(blob, l1, l2, 7, sub=0.06)
+    rng = random.Random(ord(cfg[1]))
+    pairs = []
+    for k in range(n):
+        row = rel[k] if k % 2 else blob[k]
+        s1, s2 = row[:l1].tobytes(), row[l1:].tobytes()
+        if k % 4 == 1:                       # an indel as well, so that the related pairs carry gaps
+            q = rng.randrange(10, l1 - 10)
+            s1 = s1[:q] + s1[q + 3:] + b"ACG"
+        pairs.append((s1, s2))
+    al.set_scoring(*sc, uj, sites)
+    res = al.align_batch(mode, pairs, render=False)
+    assert (res["nops"] >= 0).all()
+    for k in rng.sample(range(n), nsample):
+        r = O.align(O.MODE_NAMES[mode], pairs[k][0], pairs[k][1], *sc, uj, sites)
+        assert (int(res["score"][k]), int(res["end_i"][k]), int(res["end_j"][k]), int(res["state"][k]), res["ops"][k]) == \
+               (r["score"], r["end_i"], r["end_j"], r["state"], r["ops"]), (cfg, k)
+
+
 def test_chunked_host_entry(al):
     """Batches of >= 32k pairs go through the host entry as chunks on helper handles and threads: the results equal
     the one-piece run (AT_HOST_CHUNKS=1), ragged shapes included, and an error names the pair by its batch index."""

@@ -223,10 +223,10 @@ AT_DEV void border(int i, int j, int o16, int e16, int &L, int &M, int &U, int &
 	}
 }
 
-template <int MODE>
+template <int MODE, bool TAGS = true>
 AT_DEV int xo_of(int L, int M, int U, int J)
 {
-	int x = imax3(L | kTagL, M | kTagM, U | kTagU);
+	int x = TAGS ? imax3(L | kTagL, M | kTagM, U | kTagU) : imax3(L, M, U);
 	if constexpr (MODE == K_FITJ) x = imax(x, J);
 	return x;
 }
@@ -253,6 +253,8 @@ __global__ __launch_bounds__(64) void at_sweep(const SweepArgs a)
 	constexpr int PADW = kPad / 4;            /* s2 is staged one byte per base */
 	constexpr int RS = 64 * K;                /* rows per strip               */
 	constexpr uint32_t BMASK = (1u << BITS) - 1u;
+	/* the priority tags decide pointers, never values: kernels without a pointer matrix run without them */
+	constexpr int TgL = TB ? kTagL : 0, TgM = TB ? kTagM : 0, TgU = TB ? kTagU : 0;
 
 	const int lane = threadIdx.x;
 	Slot<SMALL> mem;
@@ -311,8 +313,8 @@ __global__ __launch_bounds__(64) void at_sweep(const SweepArgs a)
 			if constexpr (AFFINE) {
 				int L, M, U, J;
 				border<MODE>(0, j, o16, e16, L, M, U, J);
-				mem.st2(a.off_bound + 2 * j, (uint32_t)xo_of<MODE>(L, M, U, J),
-				        (uint32_t)imax((L | kTagL) + e16, (M | kTagM) + o16));
+				mem.st2(a.off_bound + 2 * j, (uint32_t)xo_of<MODE, TB>(L, M, U, J),
+				        (uint32_t)imax((L | TgL) + e16, (M | TgM) + o16));
 			} else if constexpr (MODE == K_OVERLAP) {
 				mem.st(a.off_bound + 2 * j, (uint32_t)((j == 0 ? 0 : kNeg) + o16));   /* :937-938 */
 			} else {
@@ -353,12 +355,12 @@ __global__ __launch_bounds__(64) void at_sweep(const SweepArgs a)
 				if constexpr (AFFINE) {
 					int L, M, U, J;
 					border<MODE>(i, 0, o16, e16, L, M, U, J);
-					Mo_l[r] = (M | kTagM) + o16;
-					Mg_l[r] = (M | kTagM) + g16;
-					U_l[r] = U | kTagU;
+					Mo_l[r] = (M | TgM) + o16;
+					Mg_l[r] = (M | TgM) + g16;
+					U_l[r] = U | TgU;
 					J_l[r] = J;
-					L_l[r] = L | kTagL;
-					Xl[0][r] = xo_of<MODE>(L, M, U, J);
+					L_l[r] = L | TgL;
+					Xl[0][r] = xo_of<MODE, TB>(L, M, U, J);
 					Xl[1][r] = Xl[0][r];
 				} else if constexpr (MODE == K_OVERLAP) {
 					Mo_l[r] = o16;           /* M(i,0) = 0 -> P = M + o */
@@ -372,7 +374,7 @@ __global__ __launch_bounds__(64) void at_sweep(const SweepArgs a)
 				A_prev = Xl[0][K - 1];
 				int L, M, U, J;
 				border<MODE>(base, 0, o16, e16, L, M, U, J);
-				Ad = xo_of<MODE>(L, M, U, J);
+				Ad = xo_of<MODE, TB>(L, M, U, J);
 			} else if constexpr (MODE == K_OVERLAP) {
 				A_prev = o16; Ad = o16;
 			} else {
@@ -463,15 +465,15 @@ __global__ __launch_bounds__(64) void at_sweep(const SweepArgs a)
 							if constexpr (AFFINE) {
 								int Mraw = diag + s16;
 								if constexpr (MODE == K_LOCAL) Mraw = imax(Mraw, 0);
-								const int Mc = (Mraw & ~15) | kTagM;
-								const int Lc = lraw | kTagL;
+								const int Mc = TB ? ((Mraw & ~15) | kTagM) : Mraw;
+								const int Lc = TB ? (lraw | kTagL) : lraw;
 								const int Uraw = imax(Mo_l[r], U_l[r] + e16v);
-								const int Uc = (Uraw & ~15) | kTagU;
+								const int Uc = TB ? ((Uraw & ~15) | kTagU) : Uraw;
 								int Jraw = 0, Jc = kNeg;
 								if constexpr (HASJ) {
 									const bool open_ok = (sm >> k) & 1u;
 									Jraw = open_ok ? imax(Mg_l[r], J_l[r]) : J_l[r];
-									Jc = Jraw & ~15;
+									Jc = TB ? (Jraw & ~15) : Jraw;
 								}
 								const int Mo = Mc + o16v;
 								int Xo = imax3(Lc, Mc, Uc);
@@ -587,6 +589,7 @@ __global__ __launch_bounds__(64) void at_sweep(const SweepArgs a)
 				border<MODE>(l1, l2, o16, e16, L, M, U, J);
 				eL = L | kTagL; eM = M | kTagM; eU = U | kTagU;
 			}
+			if constexpr (!TB) { eL = (eL & ~15) | kTagL; eM = (eM & ~15) | kTagM; eU = (eU & ~15) | kTagU; }   /* start state */
 			const int x = imax3(eL, eM, eU);   /* max5(L,M,U) first-wins :466 */
 			sc16 = x; st = x & 3; ci = l1; cj = l2;
 		} else if constexpr (MODE == K_FIT || MODE == K_FITJ) {

@@ -134,7 +134,11 @@ __global__ __launch_bounds__(64, AT_WAVES16(G, K)) void at_sweep16(const Sweep16
 	constexpr bool ISFIT = MODE == K_FIT || MODE == K_FITJ;
 	static_assert(TS == 4 || (TS == 2 && K <= 4), "TS = 2: the local row tag must fit 2 bits");
 	constexpr int TMASK = (1 << TS) - 1;      /* tag bits of a score */
-	constexpr int TGL = TS == 4 ? 15 : 3, TGM = TS == 4 ? 10 : 2, TGU = 1;
+	/* priority tags in the low bits of every score make v_pk_max pick the reference's first-wins candidate.  They decide
+	 * pointers, never values: the kernels without a pointer matrix (TB = false) run without them, three instructions
+	 * per row-step less, and tag the three end-cell candidates of global only to report the start state. */
+	constexpr int OTGL = TS == 4 ? 15 : 3, OTGM = TS == 4 ? 10 : 2, OTGU = 1;
+	constexpr int TGL = TB ? OTGL : 0, TGM = TB ? OTGM : 0, TGU = TB ? OTGU : 0;
 	constexpr int PB = HASJ ? 8 : 4;          /* pointer bits per cell and alignment */
 	constexpr int SPW = 16 / PB;              /* steps per pointer word (each half holds its own alignment) */
 	static_assert(G == 64 || G == 16, "group width");
@@ -335,16 +339,16 @@ __global__ __launch_bounds__(64, AT_WAVES16(G, K)) void at_sweep16(const Sweep16
 							const uint32_t S = __builtin_amdgcn_perm(lut_hi, lut_lo, selw ^ qsel[r]);
 							uint32_t Mraw = padd(diag, S);
 							if constexpr (MODE == K_LOCAL) Mraw = pmax(Mraw, 0u);
-							const uint32_t Mc = vandor(Mraw, cClean, cTagM);
-							const uint32_t Lc = lraw | cTagL;
+							const uint32_t Mc = TB ? vandor(Mraw, cClean, cTagM) : Mraw;
+							const uint32_t Lc = TB ? (lraw | cTagL) : lraw;
 							const uint32_t Uraw = pmax(Mo_l[r], padd(U_l[r], e2));
-							const uint32_t Uc = vandor(Uraw, cClean, cTagU);
+							const uint32_t Uc = TB ? vandor(Uraw, cClean, cTagU) : Uraw;
 							const uint32_t Mo = padd(Mc, o2);
 							uint32_t Xo = pmax(pmax(Lc, Mc), Uc);
 							uint32_t Jraw = 0;
 							if constexpr (HASJ) {
 								Jraw = pmax(padd(Mo_l[r], gopen), J_l[r]);     /* M first: tag 10 beats J's tag 0 on ties */
-								const uint32_t Jc = Jraw & cClean;
+								const uint32_t Jc = TB ? (Jraw & cClean) : Jraw;
 								Xo = pmax(Xo, Jc);
 								J_l[r] = Jc;
 							}
@@ -467,7 +471,7 @@ __global__ __launch_bounds__(64, AT_WAVES16(G, K)) void at_sweep16(const Sweep16
 				const int eL = half((uint32_t)__builtin_amdgcn_readlane((int)pick<K>(L_l, rl), own), h);
 				const int eM = half(psub((uint32_t)__builtin_amdgcn_readlane((int)pick<K>(Mo_l, rl), own), pk2(o16)), h);
 				const int eU = half((uint32_t)__builtin_amdgcn_readlane((int)pick<K>(U_l, rl), own), h);
-				const int x = imax3(eL, eM, eU);
+				const int x = TB ? imax3(eL, eM, eU) : imax3(eL | OTGL, eM | OTGM, eU | OTGU);   /* max5(L,M,U) first-wins :466 */
 				sc16 = x; st = x & 3; ci = l1; cj = l2;
 			} else {
 				const int own = glane + lastlane;

@@ -97,6 +97,10 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     use_dist = "RANK" in os.environ and "MASTER_ADDR" in os.environ   # launched by torch.distributed.run (any N)
+    if args.gpus != world:
+        sys.exit("bench.py: --gpus %d but WORLD_SIZE is %d -- launch N > 1 with `python -m torch.distributed.run --nnodes=1 "
+                 "--nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...` (one rank per GPU)"
+                 % (args.gpus, world))
     mode, l1, l2, pairs, scoring, use_jump, sites, seed = WORKLOADS[args.workload]
     if args.pairs:
         pairs = args.pairs

@@ -2,8 +2,9 @@
 """bench.py -- GCUPS of the batched affine-gap DP hot path on MI355X.
 
 Workload at N=1 = BASELINE.json configs[1] ("C2"): Smith-Waterman local, affine
-gap, 100k synthetic 150x150 bp pairs, scores AND tracebacks (ops strings),
-m=2 u=-2 o=-5 e=-2.  A "step" is one pass of the hot path
+gap, 100k synthetic 150x150 bp pairs, scores, tracebacks (ops strings) AND the
+reference's two gapped strings per pair rendered on the GPU, m=2 u=-2 o=-5 e=-2
+(SURVEY.md 8(d)).  A "step" is one pass of the hot path
 over the whole batch with the packed inputs already resident in HBM.
 
     python bench.py --gpus 1 --steps 200 --warmup 5
@@ -89,8 +90,11 @@ def main():
     ap.add_argument("--streams", type=int, default=3,
                     help="HIP streams (and handles) the steps alternate over: with 2, the head of step k+1 fills the SIMDs "
                          "that the draining tail of step k leaves idle")
-    ap.add_argument("--render", action="store_true",
-                    help="also turn the op codes into the two gapped strings on the GPU inside every step (at_render_batch_device)")
+    ap.add_argument("--no-cigar-gather", action="store_true", help="N > 1: gather only the fixed-size results (diagnostic)")
+    ap.add_argument("--no-gather", action="store_true", help="N > 1: no per-step collective at all (diagnostic)")
+    ap.add_argument("--no-render", action="store_true",
+                    help="stop at the op codes (CIGARs): do not also turn them into the reference's two gapped strings on the GPU "
+                         "inside every step (at_render_batch_device)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -144,7 +148,8 @@ def main():
     scl = sc.cpu().tolist()
     m, u, o, e, j, uj, ns = scl[:7]
     S = max(1, args.streams)
-    NB = max(2, S)                                   # buffer sets, used in turn
+    LAG = S                                          # the CIGAR payload of step k is sent when its stream comes round again
+    NB = S + 2                                       # buffer sets, used in turn
     als = [A.Aligner(local_rank) for _ in range(S)]  # one handle (workspace, work queue) per stream
     for x in als:
         x.set_scoring(m, u, o, e, j, bool(uj), scl[7:7 + ns])
@@ -173,14 +178,14 @@ def main():
     # (row 4 = nops, the CIGAR lengths)
     d_res2 = [torch.zeros((5, pairs), dtype=torch.int32, device=dev) for _ in range(NB)]
     d_opss = [torch.zeros(pairs * (l1 + l2) + 64, dtype=torch.uint8, device=dev) if tb else None for _ in range(S)]
-    rend = tb and args.render
+    rend = tb and not args.no_render
     d_r1s = [torch.zeros(pairs * (l1 + l2) + 64, dtype=torch.uint8, device=dev) if rend else None for _ in range(S)]
     d_r2s = [torch.zeros(pairs * (l1 + l2) + 64, dtype=torch.uint8, device=dev) if rend else None for _ in range(S)]
     gathered = [torch.empty((world * 5, pairs), dtype=torch.int32, device=dev) for _ in range(NB)] if use_dist else None
     fixed_work = [None] * NB
     # CIGAR gather: the ops slots are compacted on the GPU, the per-rank totals are gathered first,
-    # then one payload padded to the largest total.  The payload of step k travels while step k+1 computes.
-    cig = use_dist and tb
+    # then one payload padded to the largest total.  The payload of step k travels while later steps compute.
+    cig = use_dist and tb and not args.no_cigar_gather and not args.no_gather
     if cig:
         cap = pairs * (l1 + l2)
         d_packed = [torch.zeros(cap + 4096, dtype=torch.uint8, device=dev) for _ in range(NB)]
@@ -191,7 +196,6 @@ def main():
         allpay = [None] * NB
         pay_work = [None] * NB
         pay_pad = [0] * NB
-        side = torch.cuda.Stream(device=dev)
 
     def step(k):
         d_res = d_res2[k % NB]
@@ -219,7 +223,7 @@ def main():
             al.render_batch_device(pairs, d_words.data_ptr(), bits, d_woff1.data_ptr(), d_woff2.data_ptr(), d_res[1].data_ptr(),
                                    d_res[2].data_ptr(), d_ops.data_ptr(), d_ops_off.data_ptr(), d_res[4].data_ptr(),
                                    d_r1.data_ptr(), d_r2.data_ptr(), None, False, torch.cuda.current_stream().cuda_stream)
-        if not use_dist:
+        if not use_dist or args.no_gather:
             return None
         b = k % NB
         if cig:
@@ -229,18 +233,18 @@ def main():
                                   cap, d_poff[b].data_ptr(), torch.cuda.current_stream().cuda_stream)
         # gather the fixed-size results of this step; overlaps the next step's kernel
         w = dist.all_gather_into_tensor(gathered[b], d_res, async_op=True)
-        if cig:   # phase 1: every rank's payload size, brought to the host on a side stream
+        if cig:   # phase 1: every rank's payload size, brought to the host behind this step's own work
             wt = dist.all_gather_into_tensor(alltot[b], d_poff[b][pairs:], async_op=True)
-            with torch.cuda.stream(side):
-                wt.wait()
-                h_tot[b].copy_(alltot[b], non_blocking=True)
-                tot_ev[b].record(side)
+            wt.wait()
+            h_tot[b].copy_(alltot[b], non_blocking=True)
+            tot_ev[b].record()
         fixed_work[b] = w
         return w
 
     def payload(k):
-        """Phase 2 of step k's CIGAR gather, issued one step later: by then the sizes are on the host, and the
-        transfer overlaps the sweep kernel of step k+1, which is already queued."""
+        """Phase 2 of step k's CIGAR gather, issued LAG steps later: by then the sizes are on the host (the host
+        never waits for the newest launches, so several stay in flight), and the transfer overlaps the sweeps that
+        are already queued."""
         b = k % NB
         tot_ev[b].synchronize()
         pad = (max(int(h_tot[b].max()), 1) + 4095) // 4096 * 4096
@@ -248,7 +252,9 @@ def main():
         if allpay[b] is None or allpay[b].numel() < world * pad:
             allpay[b] = torch.empty(world * pad, dtype=torch.uint8, device=dev)
         pay_pad[b] = pad
-        with torch.cuda.stream(side):
+        # issued behind step k's own stream just before that stream's next sweep (step k+S) is queued: the host waits
+        # for nothing that the stream would not have to wait for anyway, and the transfer runs beside the sweeps
+        with torch.cuda.stream(streams[k % S]):
             pay_work[b] = dist.all_gather_into_tensor(allpay[b][:world * pad], d_packed[b][:pad], async_op=True)
 
     def sync_all():
@@ -270,17 +276,18 @@ def main():
     t0 = time.perf_counter()
     for k in range(args.steps):
         with torch.cuda.stream(streams[k % S]):
+            if cig and k >= LAG:
+                payload(k - LAG)
             evs[k][0].record()
             r = step(k)
             evs[k][1].record()
-            if cig and k > 0:
-                payload(k - 1)
             finish(k, r)
     for w in fixed_work:
         if w is not None:
             w.wait()
     if cig and args.steps > 0:
-        payload(args.steps - 1)
+        for k in range(max(0, args.steps - LAG), args.steps):
+            payload(k)
         for w in pay_work:
             if w is not None:
                 w.wait()
@@ -324,8 +331,19 @@ def main():
         assert (mine == slots[np.arange(l1 + l2)[None, :] < nops[:, None]]).all(), "CIGAR gather: payload differs from the ops slots"
         gather_info = {"fixed_bytes_per_rank": 20 * pairs, "cigar_bytes_per_rank": int(tots[rank]),
                        "cigar_payload_padded_to": int(pay_pad[b]), "phases": "sizes, then one padded payload; the payload of "
-                       "step k overlaps the sweep of step k+1"}
+                       "step k overlaps the sweeps of the steps queued behind it"}
     assert (scores > -(1 << 30)).all() and (nops >= 0).all(), "kernel reported a domain error"
+    if rend and args.steps > 0:
+        # the GPU-rendered strings of a sample equal what at_render (host, one pair) makes of the same ops
+        last = (args.steps - 1)
+        h_r1 = d_r1s[last % S].cpu().numpy().tobytes()
+        h_r2 = d_r2s[last % S].cpu().numpy().tobytes()
+        h_ops = d_ops.cpu().numpy()
+        h_res = d_res2[last % NB].cpu().numpy()
+        for k in range(0, pairs, max(1, pairs // 64)):
+            oo, nk = int(ops_off[k]), int(nops[k])
+            a, b = al.render(h_ops[oo:oo + nk].tobytes(), plist[k][0], int(h_res[1][k]), plist[k][1], int(h_res[2][k]))
+            assert a.encode("latin1") == h_r1[oo:oo + nk] and b.encode("latin1") == h_r2[oo:oo + nk], "rendered strings differ"
     cells_per_step = float(pairs) * l1 * l2 * world
     gcups = cells_per_step * args.steps / elapsed / 1e9
     # algorithmic HBM bytes of one launch on one GPU

@@ -584,6 +584,7 @@ static int align_device(at_handle *h, int mode, int64_t npairs,
 		memset(&b, 0, sizeof b);
 		b.npairs = npairs; b.seq = d_seq;
 		b.woff1 = (const long long *)d_woff1; b.woff2 = (const long long *)d_woff2;
+		b.len1 = d_len1; b.len2 = d_len2;
 		b.l1 = max_len1; b.l2 = max_len2;
 		const int sc = 1 << ts;
 		b.m16 = h->m * sc; b.u16 = h->u * sc; b.o16 = h->o * sc; b.e16 = h->e * sc; b.g16 = h->j * sc; b.thresh16 = thresh16;

@@ -44,6 +44,7 @@ struct Sweep16Args {
 	const uint32_t *seq;
 	const long long *woff1;
 	const long long *woff2;
+	const int *len1, *len2;        /* per pair, only to verify the caller's uniform-shape promise */
 	int l1, l2;                    /* uniform shape of the whole batch                    */
 	int m16, u16, o16, e16, g16;   /* scores * 16 (each fits int16); g16: jump penalty    */
 	const uint32_t *sitemask;      /* fit -s: bit (j + 64) set = M->J may open at column j */
@@ -189,6 +190,19 @@ __global__ __launch_bounds__(64, AT_WAVES16(G, K)) void at_sweep16(const Sweep16
 		const long long last = a.npairs - 1;
 		const long long pA = (wk * NG + grp) * 2 < a.npairs ? (wk * NG + grp) * 2 : last;
 		const long long pB = (wk * NG + grp) * 2 + 1 < a.npairs ? (wk * NG + grp) * 2 + 1 : last;
+		/* the caller promised one shape for the whole batch; a pair that breaks the promise would be swept with the
+		 * wrong extents, so its work item is refused (domain error on its pairs) instead */
+		{
+			const long long pc = wk * 2 * NG + lane;
+			const bool bad = lane < 2 * NG && pc < a.npairs && (a.len1[pc] != l1 || a.len2[pc] != l2);
+			if (__any(bad)) {
+				if (lane < 2 * NG && pc < a.npairs) {
+					a.score[pc] = INT32_MIN;
+					if (a.nops) a.nops[pc] = -1;
+				}
+				continue;
+			}
+		}
 		const uint32_t *qA = a.seq + a.woff1[pA], *qB = a.seq + a.woff1[pB];
 		const uint32_t *rA = a.seq + a.woff2[pA], *rB = a.seq + a.woff2[pB];
 

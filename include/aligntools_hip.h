@@ -104,7 +104,9 @@ int at_align_batch(at_handle *h, int mode, int64_t npairs,
  *   uniform_shape  non-zero = the caller guarantees len1[k] == max_len1 and
  *              len2[k] == max_len2 for every pair (fixed-length read batches);
  *              enables the packed two-pairs-per-wavefront kernel when the
- *              scores provably fit 16 bits.  0 is always safe.
+ *              scores provably fit 16 bits.  0 is always safe.  A pair that breaks
+ *              the promise is not swept: it and the pairs sharing its work item
+ *              (at most 8) come back with score INT32_MIN and nops -1.
  */
 int at_align_batch_device(at_handle *h, int mode, int64_t npairs,
                           const uint32_t *d_seq, int bits,

@@ -360,6 +360,39 @@ def test_baseline_shapes_at_scale(al, cfg):
                (r["score"], r["end_i"], r["end_j"], r["state"], r["ops"]), (cfg, k)
 
 
+def test_device_entry_refuses_broken_uniform_promise(al):
+    """at_align_batch_device(uniform_shape = 1) with a pair of another length: the packed kernel must not sweep it with
+    the batch extents; the pairs of that work item come back as domain errors, every other pair is unaffected."""
+    import torch
+    import aligntools.c_amd as A
+    rng = random.Random(5)
+    n, l1, l2 = 64, 150, 150
+    pairs = [("".join(rng.choice("ACGT") for _ in range(l1)).encode(), "".join(rng.choice("ACGT") for _ in range(l2)).encode()) for _ in range(n)]
+    dev = torch.device("cuda", 0)
+    words, woff1, woff2, len1, len2, bits = A.pack_pairs(pairs)
+    len1 = len1.copy()
+    len1[37] = 149
+    t = lambda a: torch.from_numpy(a).to(dev)
+    d_words, d_woff1, d_woff2, d_len1, d_len2 = t(words.view(np.int32)), t(woff1), t(woff2), t(len1), t(len2)
+    d_ops_off = t(np.arange(n, dtype=np.int64) * (l1 + l2))
+    d_res = torch.zeros((4, n), dtype=torch.int32, device=dev)
+    d_nops = torch.zeros(n, dtype=torch.int32, device=dev)
+    d_ops = torch.zeros(n * (l1 + l2) + 64, dtype=torch.uint8, device=dev)
+    al.set_scoring(2, -2, -5, -2)
+    al.align_batch_device(A.MODE_LOCAL, n, d_words.data_ptr(), bits, d_woff1.data_ptr(), d_len1.data_ptr(), d_woff2.data_ptr(),
+                          d_len2.data_ptr(), l1, l2, True, True, d_res[0].data_ptr(), d_res[1].data_ptr(), d_res[2].data_ptr(),
+                          d_res[3].data_ptr(), d_ops.data_ptr(), d_ops_off.data_ptr(), d_nops.data_ptr(),
+                          torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    assert "packed16" in al.last_config
+    score, nops = d_res[0].cpu().numpy(), d_nops.cpu().numpy()
+    refused = np.flatnonzero(score == np.iinfo(np.int32).min)
+    assert 37 in refused and len(refused) <= 8 and (nops[refused] == -1).all()
+    for k in range(n):
+        if k not in refused:
+            assert int(score[k]) == O.align(O.LOCAL, pairs[k][0], pairs[k][1], 2, -2, -5, -2)["score"]
+
+
 def test_chunked_host_entry(al):
     """Batches of >= 32k pairs go through the host entry as chunks on helper handles and threads: the results equal
     the one-piece run (AT_HOST_CHUNKS=1), ragged shapes included, and an error names the pair by its batch index."""

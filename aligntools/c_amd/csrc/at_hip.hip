@@ -642,6 +642,7 @@ static int align_device(at_handle *h, int mode, int64_t npairs,
 	});
 	if (rc) return rc;
 	a.off_ptr = pl.off_ptr; a.ws = pl.ws; a.ws_slot_words = pl.slot_words; a.queue = h->d_queue;
+	a.max_l1 = max_len1; a.max_l2 = max_len2;
 	at_sweep_fn fn = bits == 2 ? at_pick32_b2(kmode, L.k, pl.store, tb) : at_pick32_b8(kmode, L.k, pl.store, tb);
 	if (pl.dyn_lds > 48 * 1024)
 		HIP_TRY(h, hipFuncSetAttribute((const void *)fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)pl.dyn_lds));

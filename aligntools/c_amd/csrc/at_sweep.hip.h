@@ -77,6 +77,7 @@ struct SweepArgs {
 	int off_bound, off_ptr;        /* word offsets of the regions inside a slot    */
 	int off_sm, nsm;               /* fit -s: site mask words staged behind the boundary row */
 	int ptr_lanes;                 /* lanes per pointer row (min(64, ceil(max_l1/K))) */
+	int max_l1, max_l2;            /* the bounds the caller gave: the LDS / slot regions are sized from them */
 	unsigned long long *queue;     /* work counter, zeroed before every launch     */
 	/* all-vs-all mode (ap_n > 0): woff1/len1 describe ap_n READS; work item p is the ordered pair (a < b)
 	 * with linear triangle index ap_first + p; woff2/len2 are unused */
@@ -282,6 +283,14 @@ __global__ __launch_bounds__(64) void at_sweep(const SweepArgs a)
 		if (a.ap_n > 0) tri_pair(a.ap_first + p, a.ap_n, ia, ib);
 		const int l1 = uni(a.len1[ia]);
 		const int l2 = uni(a.ap_n > 0 ? a.len1[ib] : a.len2[ib]);
+		if (l1 > a.max_l1 || l2 > a.max_l2 || l1 < 0 || l2 < 0) {
+			/* longer than the bound the regions were sized from: refuse the pair instead of overrunning them */
+			if (lane == 0) {
+				a.score[p] = INT32_MIN;
+				if (a.nops) a.nops[p] = -1;
+			}
+			continue;
+		}
 		const uint32_t *q_words = a.seq + a.woff1[ia];
 		const uint32_t *r_words = a.seq + (a.ap_n > 0 ? a.woff1[ib] : a.woff2[ib]);
 		const int nstrips = (l1 + RS - 1) / RS;

@@ -100,7 +100,8 @@ int at_align_batch(at_handle *h, int mode, int64_t npairs,
  *              base k of a sequence in bits [2k%32, 2k%32+1] of word k/16) or
  *              bits = 8 (4 bytes per int32, little endian)
  *   d_woff1/2  per pair WORD offset of s1 / s2 in d_seq
- *   max_len1/2 upper bounds of len1/len2 over the batch (sizes LDS / workspace)
+ *   max_len1/2 upper bounds of len1/len2 over the batch (sizes LDS / workspace); a pair
+ *              longer than its bound is refused (score INT32_MIN, nops -1), not swept
  *   uniform_shape  non-zero = the caller guarantees len1[k] == max_len1 and
  *              len2[k] == max_len2 for every pair (fixed-length read batches);
  *              enables the packed two-pairs-per-wavefront kernel when the

@@ -391,6 +391,18 @@ def test_device_entry_refuses_broken_uniform_promise(al):
     for k in range(n):
         if k not in refused:
             assert int(score[k]) == O.align(O.LOCAL, pairs[k][0], pairs[k][1], 2, -2, -5, -2)["score"]
+    # ragged entry with bounds below the real lengths: the int32 kernel refuses the pairs instead of overrunning the
+    # regions sized from the bounds (pair 37, 149 long, fits max_len1 = 149)
+    d_res.zero_()
+    al.align_batch_device(A.MODE_LOCAL, n, d_words.data_ptr(), bits, d_woff1.data_ptr(), d_len1.data_ptr(), d_woff2.data_ptr(),
+                          d_len2.data_ptr(), 149, l2, False, True, d_res[0].data_ptr(), d_res[1].data_ptr(), d_res[2].data_ptr(),
+                          d_res[3].data_ptr(), d_ops.data_ptr(), d_ops_off.data_ptr(), d_nops.data_ptr(),
+                          torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    score, nops = d_res[0].cpu().numpy(), d_nops.cpu().numpy()
+    assert "int32" in al.last_config
+    assert [k for k in range(n) if score[k] != np.iinfo(np.int32).min] == [37] and nops[37] >= 0 and (np.delete(nops, 37) == -1).all()
+    assert int(score[37]) == O.align(O.LOCAL, pairs[37][0][:149], pairs[37][1], 2, -2, -5, -2)["score"]
 
 
 def test_chunked_host_entry(al):

@@ -1,0 +1,39 @@
+"""bench.py keeps the driver's contract: ONE JSON line on stdout with the agreed keys (a short run on the GPU box)."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+from conftest import ROOT
+
+KEYS = ["metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
+        "dtype", "data", "config", "roofline", "cpu_baseline"]
+
+
+@pytest.mark.gpu
+def test_bench_prints_one_json_line():
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "6", "--warmup", "2",
+                        "--pairs", "30000", "--no-cpu-baseline"], capture_output=True, text=True, timeout=600, env=env)
+    assert p.returncode == 0, p.stderr[-2000:]
+    lines = [x for x in p.stdout.splitlines() if x.strip()]
+    assert len(lines) == 1, p.stdout
+    d = json.loads(lines[0])
+    for k in KEYS:
+        assert k in d, k
+    assert d["unit"] == "GCUPS" and d["n_gpus"] == 1 and d["steps"] == 6 and d["warmup"] == 2 and d["higher_is_better"] is True
+    assert d["scaling"] == "weak" and d["vs_baseline"] is None and d["data"] == "synthetic" and d["dtype"] in ("int16", "int32")
+    assert "workload" in d["config"] and "model" not in d["config"]
+    r = d["roofline"]
+    for k in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
+        assert k in r, k
+    assert r["bound"] in ("hbm", "mfma") and r["unit"] == "GB/s" and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-12
+    assert d["value"] > 100 and abs(d["ms_per_step"] * d["value"] - 30000 * 150 * 150 / 1e6) < 1e-3 * d["ms_per_step"] * d["value"]
+
+
+def test_bench_refuses_gpus_without_launcher():
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2"], capture_output=True, text=True, timeout=120, env=env)
+    assert p.returncode != 0 and "torch.distributed.run" in p.stderr and p.stdout.strip() == ""

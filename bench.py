@@ -15,9 +15,10 @@ Multi-GPU: pairs are independent, so each rank aligns its own 100k-pair shard
 (weak scaling); rank 0 broadcasts the scoring block over RCCL before the timed
 region and every step's results are gathered to all ranks over RCCL: the
 fixed-size part (score, end cell, state, CIGAR length: 20 B/pair) with an
-asynchronous all_gather that overlaps the next step's kernel, the CIGARs (ops
-strings) in two phases -- compacted on the GPU, sizes first, then one padded
-payload that travels while the next step computes.
+asynchronous all_gather that overlaps the following steps' kernels, the CIGARs
+(ops strings) in two phases -- compacted on the GPU; sizes first (they are the
+gathered CIGAR lengths: every rank sums them per peer), then one padded payload
+that travels while the following steps compute.
 
 Steps alternate over `--streams` HIP streams (default 3), each with its own
 handle (workspace, work queue) and output buffers, so up to three launches are
@@ -183,8 +184,8 @@ def main():
     d_r2s = [torch.zeros(pairs * (l1 + l2) + 64, dtype=torch.uint8, device=dev) if rend else None for _ in range(S)]
     gathered = [torch.empty((world * 5, pairs), dtype=torch.int32, device=dev) for _ in range(NB)] if use_dist else None
     fixed_work = [None] * NB
-    # CIGAR gather: the ops slots are compacted on the GPU, the per-rank totals are gathered first,
-    # then one payload padded to the largest total.  The payload of step k travels while later steps compute.
+    # CIGAR gather: the ops slots are compacted on the GPU; the per-rank totals come out of the fixed-size
+    # gather (sums of the peers' CIGAR lengths); then one payload padded to the largest total.  The payload of step k travels while later steps compute.
     cig = use_dist and tb and not args.no_cigar_gather and not args.no_gather
     if cig:
         cap = pairs * (l1 + l2)
@@ -231,11 +232,11 @@ def main():
                 pay_work[b].wait()
             al.compact_ops_device(pairs, d_ops.data_ptr(), d_ops_off.data_ptr(), d_res[4].data_ptr(), d_packed[b].data_ptr(),
                                   cap, d_poff[b].data_ptr(), torch.cuda.current_stream().cuda_stream)
-        # gather the fixed-size results of this step; overlaps the next step's kernel
+        # gather the fixed-size results of this step (row 4, nops, are the CIGAR sizes: phase 1 of the CIGAR gather)
         w = dist.all_gather_into_tensor(gathered[b], d_res, async_op=True)
-        if cig:   # phase 1: every rank's payload size, brought to the host behind this step's own work
-            wt = dist.all_gather_into_tensor(alltot[b], d_poff[b][pairs:], async_op=True)
-            wt.wait()
+        if cig:   # every rank's payload size = the sum of its gathered nops, brought to the host behind this step's own work
+            w.wait()
+            torch.sum(gathered[b].view(world, 5, pairs)[:, 4, :].clamp(min=0), dim=1, dtype=torch.int64, out=alltot[b])
             h_tot[b].copy_(alltot[b], non_blocking=True)
             tot_ev[b].record()
         fixed_work[b] = w

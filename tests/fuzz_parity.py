@@ -1,0 +1,103 @@
+"""Randomised parity campaign: HIP path (through the C ABI) against the oracle restatement on freshly drawn cases --
+modes, scorings (tie-heavy, zero and large penalties), lengths, alphabets, uniform and ragged batches, jump sites,
+with and without tracebacks.  `python tests/fuzz_parity.py [cases] [seed]` on a GPU box; tests/test_fuzz.py runs a
+short campaign inside the GPU suite."""
+import os
+import random
+import sys
+
+import numpy as np
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import oracle as O   # noqa: E402  (test infrastructure)
+
+SCORINGS = [(1, -2, -5, -1, -10), (2, -2, -5, -2, -10), (1, -1, -1, -1, -1), (1, -1, -4, -1, -10), (3, -1, 0, 0, 0), (2, -3, -4, 0, -3),
+            (5, -4, -10, -1, -7), (1, 0, -1, -1, -2), (7, -5, -12, -3, -20), (0, -1, -1, -1, -1), (40, -30, -60, -20, -50)]
+ALPHABETS = ["ACGT", "ACGT", "ACGT", "AC", "A", "ACGTN", "ACDEFGHIKLMNPQRSTVWY", "ab"]
+
+
+def draw_batch(rng):
+    mode = rng.choice(["global", "local", "fit", "fit", "overlap", "edit"])
+    sc = rng.choice(SCORINGS)
+    alpha = rng.choice(ALPHABETS)
+    uj = mode == "fit" and rng.random() < 0.5
+    n = rng.choice([1, 2, 3, 7, 16, 33, 64, 100])
+    big = rng.random() < 0.06
+    hi = 1500 if big else rng.choice([8, 40, 70, 130, 200, 330])
+    if big:
+        n = min(n, 7)
+    uniform = rng.random() < 0.5
+    if uniform:
+        l1 = rng.randint(1, hi)
+        l2 = rng.randint(max(l1, 2) if mode == "fit" else 1, max(l1, 2) + hi if mode == "fit" else hi)
+        shapes = [(l1, l2)] * n
+    else:
+        shapes = []
+        for _ in range(n):
+            l1 = rng.randint(1, hi)
+            l2 = rng.randint(max(l1, 2) if mode == "fit" else 1, max(l1, 2) + hi if mode == "fit" else hi)
+            shapes.append((l1, l2))
+    pairs = []
+    for l1, l2 in shapes:
+        a = "".join(rng.choice(alpha) for _ in range(l1))
+        if rng.random() < 0.5:      # related: long tracebacks, gaps
+            t = list(a)
+            for _ in range(max(1, len(t) // 12)):
+                q = rng.randrange(len(t))
+                r = rng.random()
+                if r < 0.4:
+                    t[q] = rng.choice(alpha)
+                elif r < 0.7 and len(t) > 1:
+                    del t[q]
+                else:
+                    t.insert(q, rng.choice(alpha))
+            flank = "".join(rng.choice(alpha) for _ in range(l2))
+            cut = rng.randrange(0, max(1, l2 - len(t) + 1)) if l2 > len(t) else 0
+            b = (flank[:cut] + "".join(t) + flank)[:l2]
+        else:
+            b = "".join(rng.choice(alpha) for _ in range(l2))
+        pairs.append((a, b))
+    max_l2 = max(s[1] for s in shapes)
+    sites = sorted(rng.sample(range(max_l2 + 3), min(max_l2, rng.choice([0, 1, 3, 8])))) if uj else []
+    return mode, sc, uj, sites, pairs, rng.random() < 0.8
+
+
+def run(cases, seed, al=None, verbose=True):
+    import aligntools.c_amd as A
+    own = al is None
+    if own:
+        al = A.Aligner()
+    rng = random.Random(seed)
+    done = batches = 0
+    while done < cases:
+        mode, sc, uj, sites, pairs, tb = draw_batch(rng)
+        al.set_scoring(*sc, uj, sites)
+        try:
+            res = al.align_batch(mode, pairs, traceback=tb, render=False)
+        except A.AlignToolsError as ex:
+            # the only legitimate refusals: scores leaving the exact range (-3), inputs outside the reference's domain (-4)
+            assert ex.code in (-3, -4), (mode, sc, uj, sites, ex)
+            if ex.code == -4:
+                assert any(O.align(O.MODE_NAMES[mode], a, b, *sc, uj, sites)["rc"] != 0 for a, b in pairs), (mode, sc, pairs[:2])
+            batches += 1
+            continue
+        for k, (a, b) in enumerate(pairs):
+            r = O.align(O.MODE_NAMES[mode], a, b, *sc, uj, sites)
+            ctx = (seed, batches, mode, sc, uj, sites, k, a, b, al.last_config)
+            assert r["rc"] == 0, ctx
+            assert int(res["score"][k]) == r["score"], ctx
+            if mode != "edit":
+                assert (int(res["end_i"][k]), int(res["end_j"][k]), int(res["state"][k])) == (r["end_i"], r["end_j"], r["state"]), ctx
+                if tb:
+                    assert res["ops"][k] == r["ops"], ctx
+        done += len(pairs)
+        batches += 1
+    if own:
+        al.close()
+    if verbose:
+        print("fuzz parity: %d cases in %d batches, seed %d: all equal" % (done, batches, seed))
+    return done
+
+
+if __name__ == "__main__":
+    run(int(sys.argv[1]) if len(sys.argv) > 1 else 20000, int(sys.argv[2]) if len(sys.argv) > 2 else 1)

@@ -2,6 +2,7 @@
 reference CLI printed (tests/golden/cli.jsonl: stdout, stderr, return code), and the
 gz-FASTA reader against the record semantics of the reference's kstring_read/kseq_read.
 Error paths run anywhere; commands that align need the GPU (-m gpu)."""
+import base64
 import ctypes as C
 import gzip
 import hashlib
@@ -141,3 +142,29 @@ def test_reader_errors_like_reference(built, tmp_path):
     (tmp_path / "big.fa").write_text(">a\nACGTACGT\n>b\nACG\n")
     rc, so, se = _run(["fit", "big.fa"], tmp_path)
     assert (rc, so, se) == (255, "", "FATAL ERROR: first sequence must be shorter than the second\n\n")
+
+
+def _file_cases(need_gpu):
+    return [c for c in load_golden("cli_files.jsonl") if (c["rc"] == 0) == need_gpu]
+
+
+def _replay(case, tmp_path):
+    (tmp_path / case["file"]).write_bytes(base64.b64decode(case["data"]))
+    rc, so, se = _run(case["argv"], tmp_path)
+    assert rc == case["rc"], (case["argv"], rc, se)
+    assert se == case["stderr"], case["argv"]
+    assert so == case["stdout"], case["argv"]
+
+
+@pytest.mark.parametrize("case", _file_cases(False), ids=lambda c: " ".join(c["argv"]))
+def test_cli_input_files_error_paths(built, tmp_path, case):
+    """Reader errors on synthetic input files, recorded from the stock binary (oracle/make_cli_golden.py)."""
+    _replay(case, tmp_path)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("case", _file_cases(True), ids=lambda c: " ".join(c["argv"]))
+def test_cli_input_files_match_reference(built, tmp_path, case):
+    """Multi-line / CRLF / FASTQ / gzip / lower-case / commented inputs through every sub-command: stdout, stderr and
+    return code equal what the stock binary printed on the same files."""
+    _replay(case, tmp_path)

@@ -236,6 +236,37 @@ def test_edge_cases_empty_ragged_and_ranges(al):
     assert ei.value.code == -3
 
 
+def test_long_sequences(al):
+    """5 000 x 6 500 bases (20 strips of 256 rows, a 16 MB pointer matrix in the wave's HBM slot), unrelated and related,
+    every mode with its traceback, against the oracle."""
+    rng = random.Random(77)
+    dna = lambda n: "".join(rng.choice("ACGT") for _ in range(n))
+    a = dna(5000)
+    t = list(a)
+    for _ in range(300):
+        q = rng.randrange(len(t))
+        r = rng.random()
+        if r < 0.5:
+            t[q] = rng.choice("ACGT")
+        elif r < 0.75:
+            del t[q]
+        else:
+            t.insert(q, rng.choice("ACGT"))
+    rel = (dna(700) + "".join(t) + dna(2000))[:6500]
+    pairs = [(a, rel), (a, dna(6500))]
+    for mode, sc, uj, sites in (("global", (1, -1, -4, -1, -10), False, []), ("local", (2, -2, -5, -2, -10), False, []),
+                                ("fit", (2, -2, -5, -1, -10), False, []), ("fit", (2, -2, -5, -1, -10), True, [1000, 3000, 5000]),
+                                ("overlap", (1, -2, -5, -1, -10), False, []), ("edit", (1, 1, -5, -1, -10), False, [])):
+        al.set_scoring(*sc, uj, sites)
+        res = al.align_batch(mode, pairs, render=False)
+        for k, (x, y) in enumerate(pairs):
+            r = O.align(O.MODE_NAMES[mode], x, y, *sc, uj, sites)
+            assert int(res["score"][k]) == r["score"], (mode, uj, k)
+            if mode != "edit":
+                assert (int(res["end_i"][k]), int(res["end_j"][k]), int(res["state"][k]), res["ops"][k]) == \
+                       (r["end_i"], r["end_j"], r["state"], r["ops"]), (mode, uj, k)
+
+
 @pytest.mark.parametrize("mode", ["local", "global", "fit"])
 def test_packed16_score_range_extremes(al, mode):
     """The packed kernel keeps 16*score in int16 with a -32768 sentinel: drive it to the edges of the

@@ -283,13 +283,13 @@ struct Layout16 {
 
 /* Group width: reads of 49..208 bases run as 4 groups of 16 lanes x K rows (8 alignments per wave, 85 % of the
  * lane-steps inside a 150 x 150 matrix instead of 59 %); everything else as one group of 64 lanes. */
-static Layout16 layout16_for(bool tb, bool hasj, int l1, int l2, int ts)
+static Layout16 layout16_for(bool tb, bool hasj, int l1, int l2, int ts, bool force16 = false)
 {
 	Layout16 L;
 	const long long g_forced = env_ll("AT_GROUP", 0);
 	L.g = 64;
 	L.k = rows_per_lane(l1);
-	if (g_forced != 64 && ts == 4 && l1 > 48 && l1 <= 208) {
+	if ((force16 || (g_forced != 64 && l1 > 48)) && ts == 4 && l1 <= 208) {
 		L.g = 16;
 		L.k = l1 <= 64 ? 4 : l1 <= 80 ? 5 : l1 <= 96 ? 6 : l1 <= 112 ? 7 : (l1 <= 160 ? 10 : 13);
 	}
@@ -444,7 +444,7 @@ static int align_device(at_handle *h, int mode, int64_t npairs,
                         int32_t max_len1, int32_t max_len2, int uniform_shape, int want_traceback,
                         int32_t *d_score, int32_t *d_end_i, int32_t *d_end_j, int32_t *d_state,
                         uint8_t *d_ops, const int64_t *d_ops_off, int32_t *d_nops, void *stream_,
-                        int64_t ap_n, int64_t ap_first, const int *d_order = nullptr);
+                        int64_t ap_n, int64_t ap_first, const int *d_order = nullptr, int rag = 0);
 
 extern "C" int at_align_batch_device(at_handle *h, int mode, int64_t npairs,
                                      const uint32_t *d_seq, int bits,
@@ -536,7 +536,7 @@ static int align_device(at_handle *h, int mode, int64_t npairs,
                         int32_t max_len1, int32_t max_len2, int uniform_shape, int want_traceback,
                         int32_t *d_score, int32_t *d_end_i, int32_t *d_end_j, int32_t *d_state,
                         uint8_t *d_ops, const int64_t *d_ops_off, int32_t *d_nops, void *stream_,
-                        int64_t ap_n, int64_t ap_first, const int *d_order)
+                        int64_t ap_n, int64_t ap_first, const int *d_order, int rag)
 {
 	if (!h) return fail(nullptr, AT_ERR_ARG, "at_align_batch_device: NULL handle");
 	if (mode < AT_MODE_GLOBAL || mode > AT_MODE_EDIT) return fail(h, AT_ERR_ARG, "unknown mode %d", mode);
@@ -566,13 +566,15 @@ static int align_device(at_handle *h, int mode, int64_t npairs,
 	/* ---- packed int16 path: uniform shape, scores provably within 16 bits ---- */
 	/* scores x16 with nibble pointers when they fit (|score| < 2048), else x4 with byte pointers (|score| < 8192) */
 	int thresh16 = 0, ts = 0;
-	if (uniform_shape && ap_n == 0) {
+	if ((uniform_shape || rag) && ap_n == 0) {
 		if (packed_ok(h, mode, bits, max_len1, max_len2, 4, &thresh16)) ts = 4;
-		else if (packed_ok(h, mode, bits, max_len1, max_len2, 2, &thresh16)) ts = 2;
+		else if (!rag && packed_ok(h, mode, bits, max_len1, max_len2, 2, &thresh16)) ts = 2;
 	}
+	if (rag && (!ts || kmode != at::K_LOCAL || max_len1 > 208 || !d_order))
+		return fail(h, AT_ERR_ARG, "ragged packed launch outside its domain");   /* the host entry checks before it asks */
 	Layout16 P;
 	if (ts) {
-		P = layout16_for(tb, kmode == at::K_FITJ, max_len1, max_len2, ts);
+		P = layout16_for(tb, kmode == at::K_FITJ, max_len1, max_len2, ts, rag != 0);
 		/* A 64-lane packed wave carries 2 alignments where an int32 wave carries 1: fewer, longer work items.  A batch
 		 * that cannot give every resident wave one of them stays on the int32 kernel.  (10k x 1024^2 = 1.6 rounds: 1.96
 		 * packed vs 2.00 TCUPS int32 for a lone launch, 2.70 vs 2.13 with launches in flight; 61k pairs: 2.70 vs 2.19.) */
@@ -595,16 +597,19 @@ static int align_device(at_handle *h, int mode, int64_t npairs,
 		}
 		b.score = d_score; b.end_i = d_end_i; b.end_j = d_end_j; b.state = d_state;
 		b.ops = d_ops; b.ops_off = (const long long *)d_ops_off; b.nops = d_nops;
+		b.order = rag ? d_order : nullptr;
 		b.off_refb = P.off_refb; b.off_bound = P.off_bound; b.ptr_lanes = P.ptr_lanes; b.off_sm = P.off_sm; b.nsm = P.nsm;
 		Plan pl;
 		const int per_wave = 2 * (64 / P.g);
 		char tag16[64];
-		snprintf(tag16, sizeof tag16, "packed16 x%d %dx%d-lane groups (%d pairs/wave)", 1 << ts, 64 / P.g, P.g, per_wave);
+		snprintf(tag16, sizeof tag16, "packed16 x%d %dx%d-lane groups (%d pairs/wave)%s", 1 << ts, 64 / P.g, P.g, per_wave,
+		         rag ? " ragged frames" : "");
+		auto pick = [&](int st) { return rag ? at_pick16_rag(P.k, st, tb) : at_pick16(kmode, P.g, P.k, ts, st, tb); };
 		int rc = plan_launch(h, tag16, P.k, (npairs + per_wave - 1) / per_wave, P.off_ptr, P.words - P.off_ptr, &pl, stream,
-		                     [&](int st) { return (const void *)at_pick16(kmode, P.g, P.k, ts, st, tb); });
+		                     [&](int st) { return (const void *)pick(st); });
 		if (rc) return rc;
 		b.off_ptr = pl.off_ptr; b.ws = pl.ws; b.ws_slot_words = pl.slot_words; b.queue = h->d_queue;
-		at_sweep16_fn fn16 = at_pick16(kmode, P.g, P.k, ts, pl.store, tb);
+		at_sweep16_fn fn16 = pick(pl.store);
 		if (!fn16 || (P.g == 16 && pl.store == 2)) return fail(h, AT_ERR_RANGE, "no packed kernel for this shape (rows/lane=%d, store=%d)", P.k, pl.store);
 		if (pl.dyn_lds > 48 * 1024)
 			HIP_TRY(h, hipFuncSetAttribute((const void *)fn16, hipFuncAttributeMaxDynamicSharedMemorySize, (int)pl.dyn_lds));
@@ -783,24 +788,68 @@ static int align_host(at_handle *h, int mode, int64_t npairs, const uint8_t *seq
 	int32_t *d_st = (int32_t *)(dout + 3 * b_len1), *d_nops = (int32_t *)(dout + 4 * b_len1);
 	uint8_t *d_ops = (uint8_t *)(dout + 5 * b_len1);
 
-	/* ragged batch: hand the pairs out largest first (the work queue is dynamic, so a big pair picked up last
-	 * would otherwise run alone at the end) */
+	/* ragged batch.  Local alignments of reads (l1 <= 208, 2-bit, scores within 16 bits) go to the packed kernel in
+	 * FRAMES: pairs are sorted by (rows-per-lane class of l1, l2), cut into buckets of similar size, and every bucket is
+	 * one launch whose work items sweep the bucket's largest extents while each alignment keeps its own (RAG kernels).
+	 * Everything else: the int32 kernel, pairs handed out largest first (the work queue is dynamic, so a big pair
+	 * picked up last would otherwise run alone at the end). */
 	int *d_order = nullptr;
+	bool frames = false;
+	std::vector<int> order;
 	if (!uniform && npairs > 1 && npairs < (1LL << 31)) {
-		std::vector<int> order((size_t)npairs);
+		order.resize((size_t)npairs);
 		for (int64_t k = 0; k < npairs; ++k) order[(size_t)k] = (int)k;
-		std::stable_sort(order.begin(), order.end(), [&](int x, int y) {
-			return (int64_t)len1[x] * len2[x] > (int64_t)len1[y] * len2[y];
-		});
+		int th = 0;
+		frames = mode == AT_MODE_LOCAL && bits == 2 && max1 <= 208 && npairs >= 64 && env_ll("AT_RAGGED_PACKED", 1) &&
+		         packed_ok(h, mode, bits, max1, max2, 4, &th);
+		auto kclass = [](int l1) { return l1 <= 64 ? 4 : l1 <= 80 ? 5 : l1 <= 96 ? 6 : l1 <= 112 ? 7 : l1 <= 160 ? 10 : 13; };
+		if (frames) {
+			/* (class descending, l2 descending, index ascending): a counting sort -- the key space is 6 x (max2 + 1) */
+			auto kidx = [&](int l1) { const int kc = kclass(l1); return kc == 13 ? 0 : kc == 10 ? 1 : kc == 7 ? 2 : kc == 6 ? 3 : kc == 5 ? 4 : 5; };
+			const size_t span = (size_t)max2 + 1;
+			std::vector<int> start(6 * span + 1, 0);
+			for (int64_t k = 0; k < npairs; ++k) ++start[(size_t)kidx(len1[k]) * span + (size_t)(max2 - len2[k]) + 1];
+			for (size_t q = 1; q < start.size(); ++q) start[q] += start[q - 1];
+			for (int64_t k = 0; k < npairs; ++k) order[(size_t)start[(size_t)kidx(len1[k]) * span + (size_t)(max2 - len2[k])]++] = (int)k;
+		} else
+			std::stable_sort(order.begin(), order.end(), [&](int x, int y) {
+				return (int64_t)len1[x] * len2[x] > (int64_t)len1[y] * len2[y];
+			});
 		rc = grow(h, &h->d_order, &h->order_bytes, (size_t)npairs * 4);
 		if (rc) return rc;
 		d_order = (int *)h->d_order;
 		HIP_TRY(h, hipMemcpyAsync(d_order, order.data(), (size_t)npairs * 4, hipMemcpyHostToDevice, s));
 		HIP_TRY(h, hipStreamSynchronize(s));
+		if (frames) {
+			const int64_t min_bucket = env_ll("AT_RAGGED_MIN_BUCKET", 4096);
+			int nb = 0;
+			for (int64_t b0 = 0; b0 < npairs;) {
+				const int kc = kclass(len1[order[(size_t)b0]]);
+				const int l2first = len2[order[(size_t)b0]];
+				int64_t b1 = b0;
+				int f1 = 0;
+				while (b1 < npairs) {
+					const int x = order[(size_t)b1];
+					if (kclass(len1[x]) != kc) break;
+					if (b1 - b0 >= min_bucket && (int64_t)len2[x] * 5 < (int64_t)l2first * 4) break;   /* more than 20 % narrower */
+					f1 = std::max(f1, len1[x]);
+					++b1;
+				}
+				rc = align_device(h, mode, b1 - b0, d_words, bits, d_woff1, d_len1, d_woff2, d_len2, f1, l2first, 0, tb ? 1 : 0,
+				                  d_score, d_ei, d_ej, d_st, tb ? d_ops : nullptr, tb ? d_opsoff : nullptr, tb ? d_nops : nullptr, s,
+				                  0, 0, d_order + b0, 1);
+				if (rc) return rc;
+				b0 = b1;
+				++nb;
+			}
+			snprintf(h->cfg + strlen(h->cfg), sizeof h->cfg - strlen(h->cfg), " (%d frames)", nb);
+		}
 	}
-	rc = align_device(h, mode, npairs, d_words, bits, d_woff1, d_len1, d_woff2, d_len2, max1, max2, uniform ? 1 : 0, tb ? 1 : 0,
-	                  d_score, d_ei, d_ej, d_st, tb ? d_ops : nullptr, tb ? d_opsoff : nullptr, tb ? d_nops : nullptr, s, 0, 0, d_order);
-	if (rc) return rc;
+	if (!frames) {
+		rc = align_device(h, mode, npairs, d_words, bits, d_woff1, d_len1, d_woff2, d_len2, max1, max2, uniform ? 1 : 0, tb ? 1 : 0,
+		                  d_score, d_ei, d_ej, d_st, tb ? d_ops : nullptr, tb ? d_opsoff : nullptr, tb ? d_nops : nullptr, s, 0, 0, d_order);
+		if (rc) return rc;
+	}
 	HIP_TRY(h, hipMemcpyAsync(out_score, d_score, (size_t)npairs * 4, hipMemcpyDeviceToHost, s));
 	if (out_end_i) HIP_TRY(h, hipMemcpyAsync(out_end_i, d_ei, (size_t)npairs * 4, hipMemcpyDeviceToHost, s));
 	if (out_end_j) HIP_TRY(h, hipMemcpyAsync(out_end_j, d_ej, (size_t)npairs * 4, hipMemcpyDeviceToHost, s));

@@ -58,6 +58,9 @@ struct Sweep16Args {
 	int off_refb, off_bound, off_ptr, off_sm, nsm;   /* off_sm/nsm: site mask words staged behind the boundary row */
 	int ptr_lanes;
 	unsigned long long *queue;     /* work counter, zeroed before every launch */
+	/* RAG kernels (local, ragged batch): l1 / l2 are the FRAME every work item is swept in, len1 / len2 the pairs' own
+	 * extents (<= the frame); work item w takes pairs order[2*NG*w ...] (pairs of similar size, chosen by the host) */
+	const int *order;
 };
 
 AT_DEV uint32_t pk2(int v) { return ((uint32_t)v & 0xffffu) | ((uint32_t)v << 16); }
@@ -127,9 +130,10 @@ AT_DEV uint32_t grp_up1(uint32_t old, uint32_t src)
 	else return (uint32_t)__builtin_amdgcn_update_dpp((int)old, (int)src, 0x111 /* row_shr:1 */, 0xf, 0xf, false);
 }
 
-template <int MODE, int G, int K, int TS, bool SMALL, bool PTRLDS, bool TB>
+template <int MODE, int G, int K, int TS, bool SMALL, bool PTRLDS, bool TB, bool RAG = false>
 __global__ __launch_bounds__(64, AT_WAVES16(G, K)) void at_sweep16(const Sweep16Args a)
 {
+	static_assert(!RAG || (MODE == K_LOCAL && G == 16), "ragged frames: local, one strip");
 	static_assert(MODE == K_GLOBAL || MODE == K_LOCAL || MODE == K_FIT || MODE == K_FITJ, "packed path: the affine modes");
 	constexpr bool HASJ = MODE == K_FITJ;
 	constexpr bool ISFIT = MODE == K_FIT || MODE == K_FITJ;
@@ -188,12 +192,30 @@ __global__ __launch_bounds__(64, AT_WAVES16(G, K)) void at_sweep16(const Sweep16
 		const long long wk = wnext;
 		wnext = next_work(a.queue, lane);   /* consumed at the end of this work item: latency hidden */
 		const long long last = a.npairs - 1;
-		const long long pA = (wk * NG + grp) * 2 < a.npairs ? (wk * NG + grp) * 2 : last;
-		const long long pB = (wk * NG + grp) * 2 + 1 < a.npairs ? (wk * NG + grp) * 2 + 1 : last;
-		/* the caller promised one shape for the whole batch; a pair that breaks the promise would be swept with the
-		 * wrong extents, so its work item is refused (domain error on its pairs) instead */
-		{
+		long long pA = (wk * NG + grp) * 2 < a.npairs ? (wk * NG + grp) * 2 : last;
+		long long pB = (wk * NG + grp) * 2 + 1 < a.npairs ? (wk * NG + grp) * 2 + 1 : last;
+		int l1A = l1, l1B = l1, l2A = l2, l2B = l2;   /* the alignments' own extents (RAG: inside the frame l1 x l2) */
+		long long pout = 0;                            /* lanes 0 .. 2*NG-1: where the results of alignment `lane` go */
+		if constexpr (RAG) {
+			const long long pc = wk * 2 * NG + lane < a.npairs ? wk * 2 * NG + lane : last;
+			pout = lane < 2 * NG ? (long long)a.order[pc] : 0;
+			const int o1 = lane < 2 * NG ? a.len1[pout] : 0, o2l = lane < 2 * NG ? a.len2[pout] : 0;
+			pA = __shfl((int)pout, 2 * grp); pB = __shfl((int)pout, 2 * grp + 1);
+			l1A = __shfl(o1, 2 * grp); l1B = __shfl(o1, 2 * grp + 1);
+			l2A = __shfl(o2l, 2 * grp); l2B = __shfl(o2l, 2 * grp + 1);
+			const bool bad = lane < 2 * NG && (o1 > l1 || o2l > l2 || o1 < 1 || o2l < 1);
+			if (__any(bad)) {   /* a pair that does not fit the frame (or is empty: outside local's domain) */
+				if (lane < 2 * NG && wk * 2 * NG + lane < a.npairs) {
+					a.score[pout] = INT32_MIN;
+					if (a.nops) a.nops[pout] = -1;
+				}
+				continue;
+			}
+		} else {
+			/* the caller promised one shape for the whole batch; a pair that breaks the promise would be swept with the
+			 * wrong extents, so its work item is refused (domain error on its pairs) instead */
 			const long long pc = wk * 2 * NG + lane;
+			pout = pc;
 			const bool bad = lane < 2 * NG && pc < a.npairs && (a.len1[pc] != l1 || a.len2[pc] != l2);
 			if (__any(bad)) {
 				if (lane < 2 * NG && pc < a.npairs) {
@@ -209,8 +231,9 @@ __global__ __launch_bounds__(64, AT_WAVES16(G, K)) void at_sweep16(const Sweep16
 		/* ---- stage both s2 of my group as bytes (coalesced int32 reads of the 2-bit words) ---- */
 		{
 			const int nw2 = (l2 + 15) >> 4;
+			const int nwA = (l2A + 15) >> 4, nwB = (l2B + 15) >> 4;   /* RAG: never read behind an alignment's own words */
 			for (int w = lg; w < nw2; w += G) {
-				const uint32_t va = rA[w], vb = rB[w];
+				const uint32_t va = rA[RAG ? imin(w, nwA - 1) : w], vb = rB[RAG ? imin(w, nwB - 1) : w];
 #pragma unroll
 				for (int q = 0; q < 4; ++q) {
 					const uint32_t ba = (va >> (8 * q)) & 0xffu, bb = (vb >> (8 * q)) & 0xffu;
@@ -248,15 +271,15 @@ __global__ __launch_bounds__(64, AT_WAVES16(G, K)) void at_sweep16(const Sweep16
 			uint32_t qsel[K], acc[K], keymask[K];
 #pragma unroll
 			for (int r = 0; r < K; ++r) {
-				const int qi = imin(i0 + r, l1 - 1);
-				const uint32_t ca = (qA[qi >> 4] >> ((qi & 15) * 2)) & 3u, cb = (qB[qi >> 4] >> ((qi & 15) * 2)) & 3u;
+				const int qi = imin(i0 + r, l1A - 1), qj = imin(i0 + r, l1B - 1);
+				const uint32_t ca = (qA[qi >> 4] >> ((qi & 15) * 2)) & 3u, cb = (qB[qj >> 4] >> ((qj & 15) * 2)) & 3u;
 				/* my query bases of both alignments as the bytes {qB|4, qB, qA|4, qA}: xor-ing the s2 bytes {b,b,a,a}
 				 * onto it gives the LUT selector directly (codes are < 4, so the |4 survives the xor) */
 				qsel[r] = (ca * 0x00000101u + cb * 0x01010000u) | 0x04000400u;
 				acc[r] = 0;
 				/* rows past l1 (only in the last lane that owns rows): their key collapses to the bare row tag,
 				 * which every real row of the lane beats (smaller r = larger tag, score >= 0) */
-				keymask[r] = i0 + r < l1 ? (uint32_t)(0xffff & ~TMASK) * 0x00010001u : 0u;
+				keymask[r] = (i0 + r < l1A ? (uint32_t)(0xffff & ~TMASK) : 0u) | (i0 + r < l1B ? (uint32_t)(0xffff & ~TMASK) << 16 : 0u);
 				int L, M, U;
 				border16<MODE>(i0 + r + 1, 0, o16, e16, L, M, U);
 				L = sat16(L);
@@ -405,6 +428,12 @@ __global__ __launch_bounds__(64, AT_WAVES16(G, K)) void at_sweep16(const Sweep16
 							if constexpr (MODE != K_LOCAL) L_l[r] = Lc;
 						}
 						if constexpr (MODE == K_LOCAL) {
+							if constexpr (RAG) {
+								/* columns behind an alignment's own l2 are swept (they feed nothing inside it) but must
+								 * not win its arg-max */
+								const uint32_t cm = (((uint32_t)((jm1 - l2A) >> 31)) & 0xffffu) | (((uint32_t)((jm1 - l2B) >> 31)) << 16);
+								cmax = vbfi(cm, cmax, neg2);
+							}
 							uint32_t dlt = psub(best, cmax);
 							asm("" : "+v"(dlt));                        /* keep hipcc from turning this into 2 cmp + 2 cndmask + perm */
 							const uint32_t g = pneg(dlt);               /* 0xffff where cmax > best */
@@ -451,7 +480,7 @@ __global__ __launch_bounds__(64, AT_WAVES16(G, K)) void at_sweep16(const Sweep16
 					const int key = half(best, h);
 					const int sc = key & ~TMASK;
 					const int row = i0 + (K - 1 - (key & TMASK)) + 1;
-					if (key != kNeg16 && row <= l1 && sc > gbs[h]) {
+					if (key != kNeg16 && row <= (h == 0 ? l1A : l1B) && sc > gbs[h]) {
 						gbs[h] = sc;
 						gbi[h] = row;
 						gbj[h] = (int)((bt >> (16 * h)) & 0xffffu) - lg + 1;
@@ -504,8 +533,9 @@ __global__ __launch_bounds__(64, AT_WAVES16(G, K)) void at_sweep16(const Sweep16
 		 *                   dependent pointer loads overlap instead of queueing behind each other ================= */
 		{
 			const int g = lane >> 1, h = lane & 1;
-			const long long p = (wk * NG + g) * 2 + h;
-			const bool mine = lane < 2 * NG && p < a.npairs;
+			const long long pin = (wk * NG + g) * 2 + h;          /* = wk * 2 * NG + lane */
+			const bool mine = lane < 2 * NG && pin < a.npairs;
+			const long long p = RAG ? pout : pin;                  /* RAG: the host's order array says which pair this is */
 			if (mine) {
 				int ci = my_ci, cj = my_cj, st = my_st, cnt = 0;
 				bool ok = my_ok;

@@ -436,6 +436,50 @@ def test_device_entry_refuses_broken_uniform_promise(al):
     assert int(score[37]) == O.align(O.LOCAL, pairs[37][0][:149], pairs[37][1], 2, -2, -5, -2)["score"]
 
 
+def test_ragged_local_batches_in_frames(al):
+    """Ragged local batches of reads (l1 <= 208) run on the packed kernel in frames: sorted into buckets of similar size,
+    every alignment keeping its own extents inside its bucket's frame.  All lengths from 1 up, unrelated and related
+    pairs, score / end cell / ops against the oracle; a batch with one longer read falls back to the int32 kernel."""
+    rng = random.Random(91)
+    dna = lambda n: "".join(rng.choice("ACGT") for _ in range(n))
+    pairs = []
+    for k in range(3000):
+        l1 = rng.choice([1, 2, 15, 16, 17, 48, 49, 63, 64, 65, 80, 81, 96, 112, 113, 150, 160, 161, 207, 208]) if k % 3 == 0 else rng.randint(1, 208)
+        l2 = rng.randint(1, 260)
+        a = dna(l1)
+        if k % 2:
+            t = list(a)
+            for _ in range(max(1, l1 // 15)):
+                q = rng.randrange(len(t))
+                r = rng.random()
+                if r < 0.4:
+                    t[q] = rng.choice("ACGT")
+                elif r < 0.7 and len(t) > 1:
+                    del t[q]
+                else:
+                    t.insert(q, rng.choice("ACGT"))
+            b = (dna(rng.randint(0, 30)) + "".join(t) + dna(l2))[:max(l2, 1)]
+        else:
+            b = dna(l2)
+        pairs.append((a, b))
+    for sc in ((2, -2, -5, -2), (1, -1, -1, -1), (3, -1, 0, 0)):
+        al.set_scoring(*sc)
+        for tb in (True, False):
+            res = al.align_batch("local", pairs, traceback=tb, render=False)
+            assert "ragged frames" in al.last_config, al.last_config
+            for k, (a, b) in enumerate(pairs):
+                r = O.align(O.LOCAL, a, b, *sc)
+                assert (int(res["score"][k]), int(res["end_i"][k]), int(res["end_j"][k])) == (r["score"], r["end_i"], r["end_j"]), (sc, tb, k)
+                if tb:
+                    assert res["ops"][k] == r["ops"], (sc, k)
+    al.set_scoring(2, -2, -5, -2)
+    longer = pairs[:200] + [(dna(209), dna(100))]
+    res = al.align_batch("local", longer, render=False)
+    assert "int32" in al.last_config
+    r = O.align(O.LOCAL, longer[-1][0], longer[-1][1], 2, -2, -5, -2)
+    assert int(res["score"][-1]) == r["score"] and res["ops"][-1] == r["ops"]
+
+
 def test_chunked_host_entry(al):
     """Batches of >= 32k pairs go through the host entry as chunks on helper handles and threads: the results equal
     the one-piece run (AT_HOST_CHUNKS=1), ragged shapes included, and an error names the pair by its batch index."""

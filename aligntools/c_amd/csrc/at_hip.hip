@@ -301,7 +301,8 @@ static Layout16 layout16_for(bool tb, bool hasj, int l1, int l2, int ts, bool fo
 	long long nref = (at::kPad + (long long)tbk * blk) / 4 + 4;
 	nref = (nref + 1) & ~1LL;
 	const long long nbound = 2LL * (l2 + 2);
-	const long long nptr = tb ? nstrips * tbk * (blk / (hasj ? 2 : 4)) * L.k * L.ptr_lanes + 64 : 0;
+	/* (the HBM slot stores a lane's rows in 16-byte groups: K rounded up to a multiple of 4; the LDS form needs less) */
+	const long long nptr = tb ? nstrips * tbk * (blk / (hasj ? 2 : 4)) * ((L.k + 3) / 4 * 4) * L.ptr_lanes + 64 : 0;
 	const long long nsm = hasj ? (((long long)l2 + 64 + 64 + 128 + 31) / 32 + 2 + 1) & ~1LL : 0;
 	L.off_refb = (int)nref;
 	L.off_bound = (int)(2 * nref * ng);

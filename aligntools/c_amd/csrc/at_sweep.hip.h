@@ -187,6 +187,9 @@ struct PtrStore {
 		if constexpr (LDS) return at_lds[i];
 		else return __hip_atomic_load(g + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   /* sc1: bypasses this CU's L1 */
 	}
+	/* 16 / 8 bytes of one lane at once (global slot only; i is a multiple of 4 / 2 words) */
+	AT_DEV void st4(int i, uint32_t v0, uint32_t v1, uint32_t v2, uint32_t v3) const { *(uint4 *)(g + i) = make_uint4(v0, v1, v2, v3); }
+	AT_DEV void st2(int i, uint32_t v0, uint32_t v1) const { *(uint2 *)(g + i) = make_uint2(v0, v1); }
 	AT_DEV void ready() const   /* before the first ld of a pair */
 	{
 		if constexpr (LDS) __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");

@@ -130,6 +130,18 @@ AT_DEV uint32_t grp_up1(uint32_t old, uint32_t src)
 	else return (uint32_t)__builtin_amdgcn_update_dpp((int)old, (int)src, 0x111 /* row_shr:1 */, 0xf, 0xf, false);
 }
 
+/* Word (wr, r, lane) of a strip's pointer matrix: wr = block of SPW steps, r = row in lane.  In LDS the lanes of one
+ * (wr, r) are adjacent.  In the HBM slot four rows of a lane are adjacent, then the lanes: a lane stores 16 bytes at once
+ * (K / 4 stores per block instead of K, each covering 1 KiB of consecutive addresses), and a 128-byte line holds 8 lanes x
+ * 4 rows, so a pointer walk, which climbs one row per op, finds up to four ops in a line instead of a new line per op. */
+template <bool LDS, int K>
+AT_DEV int pidx(int wr, int r, int lane, int NL)
+{
+	constexpr int KQ = (K + 3) / 4;
+	if constexpr (LDS) return (wr * K + r) * NL + lane;
+	else return ((wr * KQ + r / 4) * NL + lane) * 4 + (r & 3);
+}
+
 template <int MODE, int G, int K, int TS, bool SMALL, bool PTRLDS, bool TB, bool RAG = false>
 __global__ __launch_bounds__(64, AT_WAVES16(G, K)) void at_sweep16(const Sweep16Args a)
 {
@@ -181,7 +193,8 @@ __global__ __launch_bounds__(64, AT_WAVES16(G, K)) void at_sweep16(const Sweep16
 	asm volatile("" : "+v"(cClean), "+v"(cTagM), "+v"(cTagL), "+v"(cTagU), "+v"(cM3), "+v"(cM7), "+v"(cNib));
 	const int nstrips = (l1 + RS - 1) / RS;   /* host guarantees 1 when G < 64 */
 	const int tbk = (l2 + G - 1 + BLK - 1) / BLK;
-	const int wps = tbk * RPB * K;            /* pointer word rows per strip */
+	constexpr int KP = PTRLDS ? K : (K + 3) / 4 * 4;   /* rows per lane as stored (HBM slot: padded to whole 16-byte groups) */
+	const int wps = tbk * RPB * KP;           /* pointer word rows per strip */
 	const int lastlane = l1 > 0 ? ((l1 - 1) % RS) / K : 0;   /* lane-in-group owning row l1 */
 	const int rl = l1 > 0 ? ((l1 - 1) % RS) % K : 0;
 	const long long nwork = (a.npairs + 2 * NG - 1) / (2 * NG);
@@ -453,8 +466,24 @@ __global__ __launch_bounds__(64, AT_WAVES16(G, K)) void at_sweep16(const Sweep16
 					Ad = Aup;
 					if constexpr (TB) {
 						if ((k + 1) % SPW == 0 && lane < NL) {
+							if constexpr (PTRLDS) {
 #pragma unroll
-							for (int r = 0; r < K; ++r) pm.st(ptr_base + ((blk * RPB + k / SPW) * K + r) * NL + lane, acc[r]);
+								for (int r = 0; r < K; ++r) pm.st(ptr_base + pidx<true, K>(blk * RPB + k / SPW, r, lane, NL), acc[r]);
+							} else {
+								const int wr = blk * RPB + k / SPW;
+#pragma unroll
+								for (int r = 0; r + 3 < K; r += 4)
+									pm.st4(ptr_base + pidx<false, K>(wr, r, lane, NL), acc[r], acc[r + 1], acc[r + 2], acc[r + 3]);
+								constexpr int R4 = K / 4 * 4;
+								if constexpr (K - R4 == 3) {
+									pm.st2(ptr_base + pidx<false, K>(wr, R4, lane, NL), acc[R4], acc[R4 + 1]);
+									pm.st(ptr_base + pidx<false, K>(wr, R4 + 2, lane, NL), acc[R4 + 2]);
+								} else if constexpr (K - R4 == 2) {
+									pm.st2(ptr_base + pidx<false, K>(wr, R4, lane, NL), acc[R4], acc[R4 + 1]);
+								} else if constexpr (K - R4 == 1) {
+									pm.st(ptr_base + pidx<false, K>(wr, R4, lane, NL), acc[R4]);
+								}
+							}
 						}
 					}
 				};
@@ -550,7 +579,7 @@ __global__ __launch_bounds__(64, AT_WAVES16(G, K)) void at_sweep16(const Sweep16
 							const int ss = (ci - 1) / RS, li = (ci - 1) % RS;
 							const int ln = li / K, r = li % K;
 							const int t = (cj - 1) + ln;
-							const uint32_t w = pm.ld(a.off_ptr + (ss * wps + (t / SPW) * K + r) * NL + glane + ln);
+							const uint32_t w = pm.ld(a.off_ptr + ss * wps * NL + pidx<PTRLDS, K>(t / SPW, r, glane + ln, NL));
 							const uint32_t nb = (w >> (16 * h + PB * (SPW - 1 - (t % SPW)))) & ((1u << PB) - 1u);
 							int op;
 							/* nibble {bit 3: U winner, bit 2: L winner, pM[1:0]} (+ bit 4: J came from M).  Bit 3 is bit 3 of the

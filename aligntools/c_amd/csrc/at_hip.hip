@@ -297,19 +297,19 @@ static Layout16 layout16_for(bool tb, bool hasj, int l1, int l2, int ts, bool fo
 	const int blk = L.g == 16 ? 4 : 8;        /* BLK of at_sweep16 */
 	const int tbk = (l2 + L.g - 1 + blk - 1) / blk;
 	L.ptr_lanes = L.g == 64 ? std::max(1, std::min(64, (l1 + L.k - 1) / L.k)) : 64;
+	L.ptr_lanes = (L.ptr_lanes + 3) & ~3;     /* the HBM slot stores 16 bytes per lane: keep every group of rows aligned */
 	const long long nstrips = (l1 + L.g * L.k - 1) / (L.g * L.k);
 	long long nref = (at::kPad + (long long)tbk * blk) / 4 + 4;
 	nref = (nref + 1) & ~1LL;
 	const long long nbound = 2LL * (l2 + 2);
-	/* (the HBM slot stores a lane's rows in 16-byte groups: K rounded up to a multiple of 4; the LDS form needs less) */
-	const long long nptr = tb ? nstrips * tbk * (blk / (hasj ? 2 : 4)) * ((L.k + 3) / 4 * 4) * L.ptr_lanes + 64 : 0;
+	const long long nptr = tb ? nstrips * tbk * (blk / (hasj ? 2 : 4)) * L.k * L.ptr_lanes + 64 : 0;
 	const long long nsm = hasj ? (((long long)l2 + 64 + 64 + 128 + 31) / 32 + 2 + 1) & ~1LL : 0;
 	L.off_refb = (int)nref;
 	L.off_bound = (int)(2 * nref * ng);
 	L.off_sm = (int)(2 * nref * ng + nbound);
 	L.nsm = (int)nsm;
-	L.off_ptr = (int)(2 * nref * ng + nbound + nsm);
-	L.words = 2 * nref * ng + nbound + nsm + nptr;
+	L.off_ptr = (int)((2 * nref * ng + nbound + nsm + 3) & ~3LL);   /* 16-byte aligned: wide pointer stores */
+	L.words = L.off_ptr + nptr;
 	return L;
 }
 

@@ -131,15 +131,16 @@ AT_DEV uint32_t grp_up1(uint32_t old, uint32_t src)
 }
 
 /* Word (wr, r, lane) of a strip's pointer matrix: wr = block of SPW steps, r = row in lane.  In LDS the lanes of one
- * (wr, r) are adjacent.  In the HBM slot four rows of a lane are adjacent, then the lanes: a lane stores 16 bytes at once
- * (K / 4 stores per block instead of K, each covering 1 KiB of consecutive addresses), and a 128-byte line holds 8 lanes x
- * 4 rows, so a pointer walk, which climbs one row per op, finds up to four ops in a line instead of a new line per op. */
+ * (wr, r) are adjacent.  In the HBM slot four rows of a lane are adjacent, then the lanes (the last K % 4 rows form a
+ * narrower group of their own): a lane stores 16 bytes at once (about K / 4 stores per block instead of K, each covering
+ * 1 KiB of consecutive addresses), and a 128-byte line holds 8 lanes x 4 rows, so a pointer walk, which climbs one row
+ * per op, finds up to four ops in a line instead of a new line per op.  NL is a multiple of 4 (16-byte alignment). */
 template <bool LDS, int K>
 AT_DEV int pidx(int wr, int r, int lane, int NL)
 {
-	constexpr int KQ = (K + 3) / 4;
+	constexpr int KF = K / 4 * 4, KR = K - KF;
 	if constexpr (LDS) return (wr * K + r) * NL + lane;
-	else return ((wr * KQ + r / 4) * NL + lane) * 4 + (r & 3);
+	else return r < KF ? wr * NL * K + (r / 4) * 4 * NL + lane * 4 + (r & 3) : wr * NL * K + KF * NL + lane * KR + (r - KF);
 }
 
 template <int MODE, int G, int K, int TS, bool SMALL, bool PTRLDS, bool TB, bool RAG = false>
@@ -193,8 +194,7 @@ __global__ __launch_bounds__(64, AT_WAVES16(G, K)) void at_sweep16(const Sweep16
 	asm volatile("" : "+v"(cClean), "+v"(cTagM), "+v"(cTagL), "+v"(cTagU), "+v"(cM3), "+v"(cM7), "+v"(cNib));
 	const int nstrips = (l1 + RS - 1) / RS;   /* host guarantees 1 when G < 64 */
 	const int tbk = (l2 + G - 1 + BLK - 1) / BLK;
-	constexpr int KP = PTRLDS ? K : (K + 3) / 4 * 4;   /* rows per lane as stored (HBM slot: padded to whole 16-byte groups) */
-	const int wps = tbk * RPB * KP;           /* pointer word rows per strip */
+	const int wps = tbk * RPB * K;            /* pointer word rows per strip */
 	const int lastlane = l1 > 0 ? ((l1 - 1) % RS) / K : 0;   /* lane-in-group owning row l1 */
 	const int rl = l1 > 0 ? ((l1 - 1) % RS) % K : 0;
 	const long long nwork = (a.npairs + 2 * NG - 1) / (2 * NG);
@@ -476,7 +476,8 @@ __global__ __launch_bounds__(64, AT_WAVES16(G, K)) void at_sweep16(const Sweep16
 									pm.st4(ptr_base + pidx<false, K>(wr, r, lane, NL), acc[r], acc[r + 1], acc[r + 2], acc[r + 3]);
 								constexpr int R4 = K / 4 * 4;
 								if constexpr (K - R4 == 3) {
-									pm.st2(ptr_base + pidx<false, K>(wr, R4, lane, NL), acc[R4], acc[R4 + 1]);
+									pm.st(ptr_base + pidx<false, K>(wr, R4, lane, NL), acc[R4]);
+									pm.st(ptr_base + pidx<false, K>(wr, R4 + 1, lane, NL), acc[R4 + 1]);
 									pm.st(ptr_base + pidx<false, K>(wr, R4 + 2, lane, NL), acc[R4 + 2]);
 								} else if constexpr (K - R4 == 2) {
 									pm.st2(ptr_base + pidx<false, K>(wr, R4, lane, NL), acc[R4], acc[R4 + 1]);

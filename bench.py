@@ -184,6 +184,9 @@ def main():
     d_r2s = [torch.zeros(pairs * (l1 + l2) + 64, dtype=torch.uint8, device=dev) if rend else None for _ in range(S)]
     gathered = [torch.empty((world * 5, pairs), dtype=torch.int32, device=dev) for _ in range(NB)] if use_dist else None
     fixed_work = [None] * NB
+    if use_dist:   # set-up, not a step: the first collective of a shape builds RCCL's channels (~0.1 s)
+        dist.all_gather_into_tensor(gathered[0], d_res2[0])
+        torch.cuda.synchronize()
     # CIGAR gather: the ops slots are compacted on the GPU; the per-rank totals come out of the fixed-size
     # gather (sums of the peers' CIGAR lengths); then one payload padded to the largest total.  The payload of step k travels while later steps compute.
     cig = use_dist and tb and not args.no_cigar_gather and not args.no_gather
@@ -194,7 +197,7 @@ def main():
         alltot = [torch.zeros(world, dtype=torch.int64, device=dev) for _ in range(NB)]
         h_tot = [torch.zeros(world, dtype=torch.int64).pin_memory() for _ in range(NB)]
         tot_ev = [torch.cuda.Event() for _ in range(NB)]
-        allpay = [None] * NB
+        allpay = [torch.empty(world * (cap + 4096), dtype=torch.uint8, device=dev) for _ in range(NB)]   # worst case, up front
         pay_work = [None] * NB
         pay_pad = [0] * NB
 
@@ -250,8 +253,6 @@ def main():
         tot_ev[b].synchronize()
         pad = (max(int(h_tot[b].max()), 1) + 4095) // 4096 * 4096
         assert pad <= cap + 4096
-        if allpay[b] is None or allpay[b].numel() < world * pad:
-            allpay[b] = torch.empty(world * pad, dtype=torch.uint8, device=dev)
         pay_pad[b] = pad
         # issued behind step k's own stream just before that stream's next sweep (step k+S) is queued: the host waits
         # for nothing that the stream would not have to wait for anyway, and the transfer runs beside the sweeps

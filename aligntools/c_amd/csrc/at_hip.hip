@@ -320,7 +320,7 @@ static bool packed_ok(const at_handle *h, int mode, int bits, int l1, int l2, in
 {
 	const long long scale = 1LL << ts;
 	if (getenv("AT_NO_PACKED") && atoi(getenv("AT_NO_PACKED"))) return false;
-	if (bits != 2 || l1 < 1 || l2 < 1) return false;
+	if ((bits != 2 && bits != 8) || l1 < 1 || l2 < 1) return false;   /* 2-bit codes: score LUT; bytes: compare */
 	if (!(mode == AT_MODE_GLOBAL || mode == AT_MODE_LOCAL || mode == AT_MODE_FIT)) return false;
 	if (h->m < 0 || h->u > 0 || h->o > 0 || h->e > 0) return false;
 	const bool hasj = mode == AT_MODE_FIT && h->use_jump;
@@ -602,10 +602,10 @@ static int align_device(at_handle *h, int mode, int64_t npairs,
 		b.off_refb = P.off_refb; b.off_bound = P.off_bound; b.ptr_lanes = P.ptr_lanes; b.off_sm = P.off_sm; b.nsm = P.nsm;
 		Plan pl;
 		const int per_wave = 2 * (64 / P.g);
-		char tag16[64];
-		snprintf(tag16, sizeof tag16, "packed16 x%d %dx%d-lane groups (%d pairs/wave)%s", 1 << ts, 64 / P.g, P.g, per_wave,
+		char tag16[112];
+		snprintf(tag16, sizeof tag16, "packed16 x%d bits=%d %dx%d-lane groups (%d pairs/wave)%s", 1 << ts, bits, 64 / P.g, P.g, per_wave,
 		         rag ? " ragged frames" : "");
-		auto pick = [&](int st) { return rag ? at_pick16_rag(P.k, st, tb) : at_pick16(kmode, P.g, P.k, ts, st, tb); };
+		auto pick = [&](int st) { return rag ? at_pick16_rag(P.k, st, tb, bits) : at_pick16(kmode, P.g, P.k, ts, st, tb, bits); };
 		int rc = plan_launch(h, tag16, P.k, (npairs + per_wave - 1) / per_wave, P.off_ptr, P.words - P.off_ptr, &pl, stream,
 		                     [&](int st) { return (const void *)pick(st); });
 		if (rc) return rc;
@@ -801,7 +801,7 @@ static int align_host(at_handle *h, int mode, int64_t npairs, const uint8_t *seq
 		order.resize((size_t)npairs);
 		for (int64_t k = 0; k < npairs; ++k) order[(size_t)k] = (int)k;
 		int th = 0;
-		frames = mode == AT_MODE_LOCAL && bits == 2 && max1 <= 208 && npairs >= 64 && env_ll("AT_RAGGED_PACKED", 1) &&
+		frames = mode == AT_MODE_LOCAL && max1 <= 208 && npairs >= 64 && env_ll("AT_RAGGED_PACKED", 1) &&
 		         packed_ok(h, mode, bits, max1, max2, 4, &th);
 		auto kclass = [](int l1) { return l1 <= 64 ? 4 : l1 <= 80 ? 5 : l1 <= 96 ? 6 : l1 <= 112 ? 7 : l1 <= 160 ? 10 : 13; };
 		if (frames) {

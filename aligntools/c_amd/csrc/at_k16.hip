@@ -1,9 +1,22 @@
 #include "at_launch.h"
-at_sweep16_fn at_pick16_g64_ts4(int kmode, int k, int store, bool tb);
-at_sweep16_fn at_pick16_g64_ts2(int kmode, int k, int store, bool tb);
-at_sweep16_fn at_pick16_g16(int kmode, int k, int store, bool tb);
-at_sweep16_fn at_pick16(int kmode, int g, int k, int ts, int store, bool tb)
+#define AT_DECL(b)                                                                 \
+	at_sweep16_fn at_pick16_g64_ts4_b##b(int kmode, int k, int store, bool tb);    \
+	at_sweep16_fn at_pick16_g64_ts2_b##b(int kmode, int k, int store, bool tb);    \
+	at_sweep16_fn at_pick16_g16_b##b(int kmode, int k, int store, bool tb);        \
+	at_sweep16_fn at_pick16_rag_impl_b##b(int k, int store, bool tb);
+AT_DECL(2)
+AT_DECL(8)
+#undef AT_DECL
+at_sweep16_fn at_pick16(int kmode, int g, int k, int ts, int store, bool tb, int bits)
 {
-	if (g == 16) return ts == 4 ? at_pick16_g16(kmode, k, store, tb) : nullptr;
-	return ts == 4 ? at_pick16_g64_ts4(kmode, k, store, tb) : at_pick16_g64_ts2(kmode, k, store, tb);
+	if (bits == 8) {
+		if (g == 16) return ts == 4 ? at_pick16_g16_b8(kmode, k, store, tb) : nullptr;
+		return ts == 4 ? at_pick16_g64_ts4_b8(kmode, k, store, tb) : at_pick16_g64_ts2_b8(kmode, k, store, tb);
+	}
+	if (g == 16) return ts == 4 ? at_pick16_g16_b2(kmode, k, store, tb) : nullptr;
+	return ts == 4 ? at_pick16_g64_ts4_b2(kmode, k, store, tb) : at_pick16_g64_ts2_b2(kmode, k, store, tb);
+}
+at_sweep16_fn at_pick16_rag(int k, int store, bool tb, int bits)
+{
+	return bits == 8 ? at_pick16_rag_impl_b8(k, store, tb) : at_pick16_rag_impl_b2(k, store, tb);
 }

@@ -4,9 +4,9 @@
 template <int MODE, int K>
 static at_sweep16_fn q3(int store, bool tb)
 {
-	if (!tb) return at::at_sweep16<MODE, 16, K, 4, true, true, false>;
-	if (store == 0) return at::at_sweep16<MODE, 16, K, 4, true, true, true>;
-	return at::at_sweep16<MODE, 16, K, 4, true, false, true>;
+	if (!tb) return at::at_sweep16<MODE, 16, K, 4, true, true, false, false, AT_BITS16>;
+	if (store == 0) return at::at_sweep16<MODE, 16, K, 4, true, true, true, false, AT_BITS16>;
+	return at::at_sweep16<MODE, 16, K, 4, true, false, true, false, AT_BITS16>;
 }
 template <int MODE>
 static at_sweep16_fn q2(int k, int store, bool tb)
@@ -17,7 +17,7 @@ static at_sweep16_fn q2(int k, int store, bool tb)
 	default: return nullptr;
 	}
 }
-at_sweep16_fn at_pick16_g16b(int kmode, int k, int store, bool tb)
+at_sweep16_fn AT_NAME(at_pick16_g16b)(int kmode, int k, int store, bool tb)
 {
 	switch (kmode) {
 	case at::K_GLOBAL: return q2<at::K_GLOBAL>(k, store, tb);

@@ -3,10 +3,10 @@
 template <int MODE, int K>
 static at_sweep16_fn p3(int store, bool tb)
 {
-	if (!tb) return store < 2 ? at::at_sweep16<MODE, 64, K, 2, true, true, false> : at::at_sweep16<MODE, 64, K, 2, false, false, false>;
-	if (store == 0) return at::at_sweep16<MODE, 64, K, 2, true, true, true>;
-	if (store == 1) return at::at_sweep16<MODE, 64, K, 2, true, false, true>;
-	return at::at_sweep16<MODE, 64, K, 2, false, false, true>;
+	if (!tb) return store < 2 ? at::at_sweep16<MODE, 64, K, 2, true, true, false, false, AT_BITS16> : at::at_sweep16<MODE, 64, K, 2, false, false, false, false, AT_BITS16>;
+	if (store == 0) return at::at_sweep16<MODE, 64, K, 2, true, true, true, false, AT_BITS16>;
+	if (store == 1) return at::at_sweep16<MODE, 64, K, 2, true, false, true, false, AT_BITS16>;
+	return at::at_sweep16<MODE, 64, K, 2, false, false, true, false, AT_BITS16>;
 }
 template <int MODE>
 static at_sweep16_fn p2(int k, int store, bool tb)
@@ -18,7 +18,7 @@ static at_sweep16_fn p2(int k, int store, bool tb)
 	default: return p3<MODE, 4>(store, tb);
 	}
 }
-at_sweep16_fn at_pick16_g64_ts2(int kmode, int k, int store, bool tb)
+at_sweep16_fn AT_NAME(at_pick16_g64_ts2)(int kmode, int k, int store, bool tb)
 {
 	switch (kmode) {
 	case at::K_GLOBAL: return p2<at::K_GLOBAL>(k, store, tb);

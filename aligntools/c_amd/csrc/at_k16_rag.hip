@@ -4,11 +4,11 @@
 template <int K>
 static at_sweep16_fn r3(int store, bool tb)
 {
-	if (!tb) return at::at_sweep16<at::K_LOCAL, 16, K, 4, true, true, false, true>;
-	if (store == 0) return at::at_sweep16<at::K_LOCAL, 16, K, 4, true, true, true, true>;
-	return at::at_sweep16<at::K_LOCAL, 16, K, 4, true, false, true, true>;
+	if (!tb) return at::at_sweep16<at::K_LOCAL, 16, K, 4, true, true, false, true, AT_BITS16>;
+	if (store == 0) return at::at_sweep16<at::K_LOCAL, 16, K, 4, true, true, true, true, AT_BITS16>;
+	return at::at_sweep16<at::K_LOCAL, 16, K, 4, true, false, true, true, AT_BITS16>;
 }
-at_sweep16_fn at_pick16_rag(int k, int store, bool tb)
+at_sweep16_fn AT_NAME(at_pick16_rag_impl)(int k, int store, bool tb)
 {
 	switch (k) {
 	case 4: return r3<4>(store, tb);

@@ -9,8 +9,16 @@ typedef void (*at_sweep16_fn)(const at::Sweep16Args);
 /* store: 0 = everything in LDS, 1 = s2/boundary in LDS + pointers in the global slot, 2 = everything global */
 at_sweep_fn at_pick32_b2(int kmode, int k, int store, bool tb);
 at_sweep_fn at_pick32_b8(int kmode, int k, int store, bool tb);
-at_sweep16_fn at_pick16_rag(int k, int store, bool tb);   /* local, ragged frames: k in {4,5,6,7,10,13} */
-at_sweep16_fn at_pick16(int kmode, int g, int k, int ts, int store, bool tb);   /* g: lanes per group (64 or 16); ts: 4 (x16) or 2 (x4) */   /* kmode in {K_GLOBAL, K_LOCAL, K_FIT} */
+at_sweep16_fn at_pick16_rag(int k, int store, bool tb, int bits);   /* local, ragged frames: k in {4,5,6,7,10,13} */
+at_sweep16_fn at_pick16(int kmode, int g, int k, int ts, int store, bool tb, int bits);
+/* every packed translation unit is compiled twice: -DAT_BITS16=2 (16 codes per sequence word, score LUT) and
+ * -DAT_BITS16=8 (4 bytes per word, compare); its entry points carry the suffix _b2 / _b8 */
+#ifndef AT_BITS16
+#define AT_BITS16 2
+#endif
+#define AT_CAT_(a, b) a##b
+#define AT_CAT(a, b) AT_CAT_(a, b)
+#define AT_NAME(f) AT_CAT(f, AT_CAT(_b, AT_BITS16))   /* g: lanes per group (64 or 16); ts: 4 (x16) or 2 (x4) */   /* kmode in {K_GLOBAL, K_LOCAL, K_FIT} */
 
 template <int MODE, int BITS, int K>
 static at_sweep_fn at_pick3(int store, bool tb)

@@ -64,6 +64,18 @@ struct Sweep16Args {
 };
 
 AT_DEV uint32_t pk2(int v) { return ((uint32_t)v & 0xffffu) | ((uint32_t)v << 16); }
+AT_DEV uint32_t pminu(uint32_t a, uint32_t b)
+{
+	uint32_t d;
+	asm("v_pk_min_u16 %0, %1, %2" : "=v"(d) : "v"(a), "v"(b));
+	return d;
+}
+AT_DEV uint32_t pmad(uint32_t a, uint32_t b, uint32_t c)   /* per half: a * b + c (low 16 bits) */
+{
+	uint32_t d;
+	asm("v_pk_mad_i16 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "v"(c));
+	return d;
+}
 AT_DEV uint32_t padd(uint32_t a, uint32_t b)
 {
 	return __builtin_bit_cast(uint32_t, __builtin_elementwise_add_sat(__builtin_bit_cast(s16x2, a), __builtin_bit_cast(s16x2, b)));
@@ -143,9 +155,10 @@ AT_DEV int pidx(int wr, int r, int lane, int NL)
 	else return r < KF ? wr * NL * K + (r / 4) * 4 * NL + lane * 4 + (r & 3) : wr * NL * K + KF * NL + lane * KR + (r - KF);
 }
 
-template <int MODE, int G, int K, int TS, bool SMALL, bool PTRLDS, bool TB, bool RAG = false>
+template <int MODE, int G, int K, int TS, bool SMALL, bool PTRLDS, bool TB, bool RAG = false, int BITS = 2>
 __global__ __launch_bounds__(64, AT_WAVES16(G, K)) void at_sweep16(const Sweep16Args a)
 {
+	static_assert(BITS == 2 || BITS == 8, "sequence words: 16 two-bit codes or 4 bytes");
 	static_assert(!RAG || (MODE == K_LOCAL && G == 16), "ragged frames: local, one strip");
 	static_assert(MODE == K_GLOBAL || MODE == K_LOCAL || MODE == K_FIT || MODE == K_FITJ, "packed path: the affine modes");
 	constexpr bool HASJ = MODE == K_FITJ;
@@ -190,6 +203,8 @@ __global__ __launch_bounds__(64, AT_WAVES16(G, K)) void at_sweep16(const Sweep16
 	 * the left state holds M + o, so the opening candidate is (M + o) + (g - o), or -inf where opening is barred */
 	uint32_t gmo2 = pk2(a.g16 - a.o16), neg2 = 0x80008000u;
 	asm volatile("" : "+v"(c8), "+v"(gmo2), "+v"(neg2));
+	uint32_t c1 = 0x00010001u, umm2 = pk2(a.u16 - a.m16), m2 = pk2(a.m16);   /* 8-bit alphabets: compare instead of LUT */
+	asm volatile("" : "+v"(c1), "+v"(umm2), "+v"(m2));
 	asm volatile("" : "+v"(o2), "+v"(e2), "+v"(lut_lo), "+v"(lut_hi));
 	asm volatile("" : "+v"(cClean), "+v"(cTagM), "+v"(cTagL), "+v"(cTagU), "+v"(cM3), "+v"(cM7), "+v"(cNib));
 	const int nstrips = (l1 + RS - 1) / RS;   /* host guarantees 1 when G < 64 */
@@ -243,15 +258,21 @@ __global__ __launch_bounds__(64, AT_WAVES16(G, K)) void at_sweep16(const Sweep16
 
 		/* ---- stage both s2 of my group as bytes (coalesced int32 reads of the 2-bit words) ---- */
 		{
-			const int nw2 = (l2 + 15) >> 4;
-			const int nwA = (l2A + 15) >> 4, nwB = (l2B + 15) >> 4;   /* RAG: never read behind an alignment's own words */
+			constexpr int BPW = 32 / BITS;         /* bases per sequence word */
+			const int nw2 = (l2 + BPW - 1) / BPW;
+			const int nwA = (l2A + BPW - 1) / BPW, nwB = (l2B + BPW - 1) / BPW;   /* RAG: never read behind an alignment's own words */
 			for (int w = lg; w < nw2; w += G) {
 				const uint32_t va = rA[RAG ? imin(w, nwA - 1) : w], vb = rB[RAG ? imin(w, nwB - 1) : w];
+				if constexpr (BITS == 8) {         /* already one byte per base */
+					mem.st(refoff + PADW + w, va);
+					mem.st(refoff + a.off_refb + PADW + w, vb);
+				} else {
 #pragma unroll
-				for (int q = 0; q < 4; ++q) {
-					const uint32_t ba = (va >> (8 * q)) & 0xffu, bb = (vb >> (8 * q)) & 0xffu;
-					mem.st(refoff + PADW + 4 * w + q, (ba & 3u) | ((ba & 0xcu) << 6) | ((ba & 0x30u) << 12) | ((ba & 0xc0u) << 18));
-					mem.st(refoff + a.off_refb + PADW + 4 * w + q, (bb & 3u) | ((bb & 0xcu) << 6) | ((bb & 0x30u) << 12) | ((bb & 0xc0u) << 18));
+					for (int q = 0; q < 4; ++q) {
+						const uint32_t ba = (va >> (8 * q)) & 0xffu, bb = (vb >> (8 * q)) & 0xffu;
+						mem.st(refoff + PADW + 4 * w + q, (ba & 3u) | ((ba & 0xcu) << 6) | ((ba & 0x30u) << 12) | ((ba & 0xc0u) << 18));
+						mem.st(refoff + a.off_refb + PADW + 4 * w + q, (bb & 3u) | ((bb & 0xcu) << 6) | ((bb & 0x30u) << 12) | ((bb & 0xc0u) << 18));
+					}
 				}
 			}
 		}
@@ -285,10 +306,12 @@ __global__ __launch_bounds__(64, AT_WAVES16(G, K)) void at_sweep16(const Sweep16
 #pragma unroll
 			for (int r = 0; r < K; ++r) {
 				const int qi = imin(i0 + r, l1A - 1), qj = imin(i0 + r, l1B - 1);
-				const uint32_t ca = (qA[qi >> 4] >> ((qi & 15) * 2)) & 3u, cb = (qB[qj >> 4] >> ((qj & 15) * 2)) & 3u;
+				uint32_t ca, cb;
+				if constexpr (BITS == 2) { ca = (qA[qi >> 4] >> ((qi & 15) * 2)) & 3u; cb = (qB[qj >> 4] >> ((qj & 15) * 2)) & 3u; }
+				else { ca = (qA[qi >> 2] >> ((qi & 3) * 8)) & 0xffu; cb = (qB[qj >> 2] >> ((qj & 3) * 8)) & 0xffu; }
 				/* my query bases of both alignments as the bytes {qB|4, qB, qA|4, qA}: xor-ing the s2 bytes {b,b,a,a}
 				 * onto it gives the LUT selector directly (codes are < 4, so the |4 survives the xor) */
-				qsel[r] = (ca * 0x00000101u + cb * 0x01010000u) | 0x04000400u;
+				qsel[r] = (ca * 0x00000101u + cb * 0x01010000u) | (BITS == 2 ? 0x04000400u : 0u);
 				acc[r] = 0;
 				/* rows past l1 (only in the last lane that owns rows): their key collapses to the bare row tag,
 				 * which every real row of the lane beats (smaller r = larger tag, score >= 0) */
@@ -386,7 +409,14 @@ __global__ __launch_bounds__(64, AT_WAVES16(G, K)) void at_sweep16(const Sweep16
 #pragma unroll
 						for (int r = 0; r < K; ++r) {
 							/* x = s2 byte ^ query byte (0 = match): selector {xB+4, xB, xA+4, xA} -> the two 16-bit scores */
-							const uint32_t S = __builtin_amdgcn_perm(lut_hi, lut_lo, selw ^ qsel[r]);
+							uint32_t S;
+							if constexpr (BITS == 2) {
+								S = __builtin_amdgcn_perm(lut_hi, lut_lo, selw ^ qsel[r]);
+							} else {
+								/* bytes: x = {b^qB, b^qB, a^qA, a^qA}; per 16-bit half 0 = match.  z = min(x, 1), S = m + z * (u - m) */
+								const uint32_t z = pminu(selw ^ qsel[r], c1);
+								S = pmad(z, umm2, m2);
+							}
 							uint32_t Mraw = padd(diag, S);
 							if constexpr (MODE == K_LOCAL) Mraw = pmax(Mraw, 0u);
 							const uint32_t Mc = TB ? vandor(Mraw, cClean, cTagM) : Mraw;

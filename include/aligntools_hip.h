@@ -71,8 +71,8 @@ int at_set_scoring(at_handle *h, int m, int u, int o, int e, int j,
 /*
  * Align a batch of independent pairs held in HOST memory.
  *   seq_blob          raw sequence bytes (any alphabet; compared by byte
- *                     equality like alignment.h:449).  All-ACGT batches take
- *                     the 2-bit packed path, others the 8-bit path, both on GPU.
+ *                     equality like alignment.h:449).  All-ACGT batches are packed
+ *                     2 bits per base, others 8 bits, both on the GPU.
  *   off1/len1, off2/len2   per pair: byte offset and length of s1 and s2
  *   want_traceback    0 = scores and end cells only
  *   out_score[n]      reference return value (align_*: the double, always an

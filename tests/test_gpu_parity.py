@@ -436,6 +436,40 @@ def test_device_entry_refuses_broken_uniform_promise(al):
     assert int(score[37]) == O.align(O.LOCAL, pairs[37][0][:149], pairs[37][1], 2, -2, -5, -2)["score"]
 
 
+def test_packed_kernels_on_byte_alphabets(al):
+    """Uniform batches whose sequences are not pure ACGT (reads with N, lower case, protein) run on the packed kernels with
+    byte sequence words (compare instead of the 2-bit score LUT): every mode, with tracebacks, against the oracle."""
+    rng = random.Random(123)
+    for alpha, l1, l2 in (("ACGTN", 150, 150), ("ACDEFGHIKLMNPQRSTVWY", 90, 120), ("acgtACGT", 64, 200), ("ACGTN", 300, 340)):
+        pairs = []
+        for k in range(120):
+            a = "".join(rng.choice(alpha) for _ in range(l1))
+            if k % 2:
+                t = list(a)
+                for _ in range(l1 // 20):
+                    q = rng.randrange(len(t))
+                    r = rng.random()
+                    if r < 0.5:
+                        t[q] = rng.choice(alpha)
+                    elif r < 0.75:
+                        del t[q]
+                    else:
+                        t.insert(q, rng.choice(alpha))
+                b = ("".join(rng.choice(alpha) for _ in range(20)) + "".join(t) + "".join(rng.choice(alpha) for _ in range(l2)))[:l2]
+            else:
+                b = "".join(rng.choice(alpha) for _ in range(l2))
+            pairs.append((a, b))
+        for mode, sc, uj, sites in (("local", (2, -2, -5, -2, -10), False, []), ("global", (1, -1, -4, -1, -10), False, []),
+                                    ("fit", (2, -2, -5, -1, -10), False, []), ("fit", (2, -2, -5, -1, -8), True, [10, 50, 100])):
+            al.set_scoring(*sc, uj, sites)
+            res = al.align_batch(mode, pairs, render=False)
+            assert "packed16" in al.last_config and "bits=8" in al.last_config, al.last_config
+            for k, (x, y) in enumerate(pairs):
+                r = O.align(O.MODE_NAMES[mode], x, y, *sc, uj, sites)
+                assert (int(res["score"][k]), int(res["end_i"][k]), int(res["end_j"][k]), int(res["state"][k]), res["ops"][k]) == \
+                       (r["score"], r["end_i"], r["end_j"], r["state"], r["ops"]), (alpha, mode, uj, k)
+
+
 def test_ragged_local_batches_in_frames(al):
     """Ragged local batches of reads (l1 <= 208) run on the packed kernel in frames: sorted into buckets of similar size,
     every alignment keeping its own extents inside its bucket's frame.  All lengths from 1 up, unrelated and related

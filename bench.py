@@ -91,6 +91,9 @@ def main():
     ap.add_argument("--streams", type=int, default=3,
                     help="HIP streams (and handles) the steps alternate over: with 2, the head of step k+1 fills the SIMDs "
                          "that the draining tail of step k leaves idle")
+    ap.add_argument("--bits", type=int, default=0, choices=[0, 2, 8],
+                    help="sequence words: 0 = 2-bit when the batch is pure ACGT (it is), 8 = force byte words (the kernels for "
+                         "reads with N / protein)")
     ap.add_argument("--no-cigar-gather", action="store_true", help="N > 1: gather only the fixed-size results (diagnostic)")
     ap.add_argument("--no-gather", action="store_true", help="N > 1: no per-step collective at all (diagnostic)")
     ap.add_argument("--no-render", action="store_true",
@@ -166,7 +169,7 @@ def main():
     else:
         blob = synth_pairs_blob(seed, pairs, l1, l2, first_pair=rank * pairs)
         plist = [(row[:l1].tobytes(), row[l1:].tobytes()) for row in blob]
-    words, woff1, woff2, len1, len2, bits = A.pack_pairs(plist)
+    words, woff1, woff2, len1, len2, bits = A.pack_pairs(plist, bits=args.bits)
     tb = (not args.no_traceback) and mode != "edit" and not allpairs
     d_words = torch.from_numpy(words.view(np.int32)).to(dev)
     d_woff1 = torch.from_numpy(woff1).to(dev)

@@ -685,3 +685,48 @@ def test_gpu_rendering_device_entry_full_size(al):
         so, oo, nk = k * (l1 + l2 + 1), k * (l1 + l2), int(nops[k])
         assert q1[oo:oo + nk] == r1[so:so + nk] and q2[oo:oo + nk] == r2[so:so + nk]
         assert nk == l1 + l2 or q1[oo + nk] == 0x7f           # nothing written behind the string
+
+
+def test_all_vs_all_scores_long_reads(al):
+    """The C5 arrangement proper: all-vs-all overlap SCORES over reads of about 1 kbp (16 rows per lane, one strip, no
+    pointer matrix), pairs enumerated on the GPU; score and end cell of every pair equal the oracle's."""
+    import torch
+    import aligntools.c_amd as A
+    rng = random.Random(32)
+    genome = "".join(rng.choice("ACGT") for _ in range(6000))
+    reads = []
+    for k in range(24):
+        st = rng.randint(0, 5000)
+        r = list(genome[st:st + rng.randint(700, 1000)])
+        for _ in range(len(r) // 40):                       # sequencing errors
+            q = rng.randrange(len(r))
+            x = rng.random()
+            if x < 0.5:
+                r[q] = rng.choice("ACGT")
+            elif x < 0.75:
+                del r[q]
+            else:
+                r.insert(q, rng.choice("ACGT"))
+        reads.append("".join(r))
+    n = len(reads)
+    words, woff, _w2, lens, _l2, bits = A.pack_pairs([(r.encode(), b"") for r in reads])
+    dev = torch.device("cuda", 0)
+    d_words, d_woff, d_len = (torch.from_numpy(x).to(dev) for x in (words.view(np.int32), woff, lens))
+    total = n * (n - 1) // 2
+    res = torch.zeros((4, total), dtype=torch.int32, device=dev)
+    al.set_scoring(1, -2, -5, -1)
+    al.align_allpairs_device(A.MODE_OVERLAP, n, d_words.data_ptr(), bits, d_woff.data_ptr(), d_len.data_ptr(), int(lens.max()),
+                             0, total, False, res[0].data_ptr(), res[1].data_ptr(), res[2].data_ptr(), res[3].data_ptr(),
+                             None, None, None, torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    assert "rows/lane=16" in al.last_config, al.last_config
+    r = res.cpu().numpy()
+    t = 0
+    positive = 0
+    for a in range(n):
+        for b in range(a + 1, n):
+            ref = O.align(O.OVERLAP, reads[a], reads[b], 1, -2, -5, -1)
+            assert (int(r[0, t]), int(r[1, t]), int(r[2, t])) == (ref["score"], ref["end_i"], ref["end_j"]), (a, b)
+            positive += ref["score"] > 50
+            t += 1
+    assert positive >= 5       # real overlaps are in the set

@@ -7,6 +7,7 @@
 #include "at_launch.h"
 #include "at_pack.hip.h"
 #include "at_render.hip.h"
+#include "at_myers.hip.h"
 #include "../../../include/aligntools_hip.h"
 
 #include <algorithm>
@@ -618,6 +619,34 @@ static int align_device(at_handle *h, int mode, int64_t npairs,
 		HIP_TRY(h, hipGetLastError());
 		/* (Tried and dropped: sweeping the remainder of a batch that is not a multiple of resident-waves x 8 with a
 		 * second, finer-grained launch -- the second launch costs as much as the lone last round it replaces.) */
+		return AT_OK;
+	}
+
+	/* ---- edit distance with unit mismatch cost: bit-parallel kernel (at_myers.hip.h), any mix of lengths ---- */
+	if (kmode == at::K_EDIT && h->u == 1 && bits == 2 && ap_n == 0 && max_len1 <= 8192 && env_ll("AT_MYERS", 1)) {
+		const int g = max_len1 <= 256 ? 8 : 32;            /* lanes per alignment */
+		const int w = max_len1 <= 1024 ? 1 : max_len1 <= 2048 ? 2 : max_len1 <= 4096 ? 4 : 8;
+		at_myers_fn fn = at_pick_myers(w, g);
+		const int per_wave = 64 / g;
+		at::MyersArgs m;
+		memset(&m, 0, sizeof m);
+		m.npairs = npairs; m.seq = d_seq;
+		m.woff1 = (const long long *)d_woff1; m.woff2 = (const long long *)d_woff2; m.len1 = d_len1; m.len2 = d_len2;
+		m.max_l1 = max_len1; m.max_l2 = max_len2;
+		m.score = d_score; m.end_i = d_end_i; m.end_j = d_end_j; m.state = d_state; m.nops = d_nops;
+		m.order = d_order;
+		if (!h->d_queue) HIP_TRY(h, hipMalloc((void **)&h->d_queue, 64));
+		HIP_TRY(h, hipMemsetAsync(h->d_queue, 0, 8, stream));
+		m.queue = h->d_queue;
+		const size_t lds = (size_t)per_wave * (((size_t)max_len2 + 15) / 16 + 2) * 4;
+		if (lds > 60 * 1024) return fail(h, AT_ERR_RANGE, "second sequence too long for the bit-parallel kernel's LDS window");
+		int occ = 0;
+		if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, (const void *)fn, 64, lds) != hipSuccess || occ <= 0) occ = 8;
+		const long long grid = std::max(1LL, std::min<long long>((npairs + per_wave - 1) / per_wave, (long long)occ * h->ncu));
+		hipLaunchKernelGGL(fn, dim3((unsigned)grid), dim3(64), lds, stream, m);
+		HIP_TRY(h, hipGetLastError());
+		snprintf(h->cfg, sizeof h->cfg, "myers bits=2 words/lane=%d %dx%d-lane groups (%d pairs/wave) lds=%zuB waves/cu<=%d grid=%lld", w, per_wave, g, per_wave,
+		         lds, occ, grid);
 		return AT_OK;
 	}
 

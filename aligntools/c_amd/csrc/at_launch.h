@@ -5,6 +5,9 @@
 
 typedef void (*at_sweep_fn)(const at::SweepArgs);
 typedef void (*at_sweep16_fn)(const at::Sweep16Args);
+namespace at { struct MyersArgs; }
+typedef void (*at_myers_fn)(const at::MyersArgs);
+at_myers_fn at_pick_myers(int w, int g);   /* w in {1,2,4,8} 32-bit words per lane, g in {32, 8} lanes per alignment */
 
 /* store: 0 = everything in LDS, 1 = s2/boundary in LDS + pointers in the global slot, 2 = everything global */
 at_sweep_fn at_pick32_b2(int kmode, int k, int store, bool tb);

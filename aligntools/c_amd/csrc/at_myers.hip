@@ -1,0 +1,14 @@
+#include "at_myers.hip.h"
+#include "at_launch.h"
+/* bit-parallel edit distance: W words of 32 rows per lane, G lanes per alignment (l1 <= 32 * G * W) */
+at_myers_fn at_pick_myers(int w, int g)
+{
+	if (g == 8) return w == 1 ? at::at_myers<1, 8> : nullptr;   /* reads up to 256 bases, 8 alignments per wavefront */
+	switch (w) {
+	case 1: return at::at_myers<1, 32>;
+	case 2: return at::at_myers<2, 32>;
+	case 4: return at::at_myers<4, 32>;
+	case 8: return at::at_myers<8, 32>;
+	default: return nullptr;
+	}
+}

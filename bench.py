@@ -54,6 +54,9 @@ WORKLOADS = {
     # all-vs-all over 50k reads of 1 kbp (1.25e9 ordered pairs in full): each step scores a 100k-pair slice of the
     # triangle per GPU, pairs enumerated on the GPU (at_align_allpairs_device), scores + end cells only
     "C5all": ("overlap", 1000, 1000, 100000, (1, -2, -5, -1, -10), False, [], 0x5EED0005),
+    # edit distance with unit mismatch cost (`edit -u 1`): the bit-parallel kernel; "cells" are the DP cells it stands for
+    "E1k": ("edit", 1000, 1000, 100000, (1, 1, -5, -1, -10), False, [], 0x5EED0006),
+    "E150": ("edit", 150, 150, 400000, (1, 1, -5, -1, -10), False, [], 0x5EED0007),
 }
 
 

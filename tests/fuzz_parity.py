@@ -12,7 +12,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import oracle as O   # noqa: E402  (test infrastructure)
 
 SCORINGS = [(1, -2, -5, -1, -10), (2, -2, -5, -2, -10), (1, -1, -1, -1, -1), (1, -1, -4, -1, -10), (3, -1, 0, 0, 0), (2, -3, -4, 0, -3),
-            (5, -4, -10, -1, -7), (1, 0, -1, -1, -2), (7, -5, -12, -3, -20), (0, -1, -1, -1, -1), (40, -30, -60, -20, -50)]
+            (5, -4, -10, -1, -7), (1, 0, -1, -1, -2), (7, -5, -12, -3, -20), (0, -1, -1, -1, -1), (40, -30, -60, -20, -50), (2, 1, -3, -1, -5)]
 ALPHABETS = ["ACGT", "ACGT", "ACGT", "AC", "A", "ACGTN", "ACDEFGHIKLMNPQRSTVWY", "ab"]
 
 

@@ -352,7 +352,10 @@ def test_deep_lane_kernels_overlap_scores_and_edit(al):
         for mode, sc in (("overlap", (1, -2, -5, -1)), ("overlap", (2, -3, -4, -1)), ("edit", (1, 1, -5, -1)), ("edit", (1, -2, -5, -1))):
             al.set_scoring(*sc)
             res = al.align_batch(mode, pairs, traceback=False)
-            assert "rows/lane=8" in al.last_config or "rows/lane=16" in al.last_config, al.last_config
+            if mode == "edit" and sc[1] == 1 and all(set(a + b) <= set("ACGT") for a, b in pairs):
+                assert "myers" in al.last_config, al.last_config          # unit costs on DNA: the bit-parallel kernel
+            else:
+                assert "rows/lane=8" in al.last_config or "rows/lane=16" in al.last_config, al.last_config
             for k, (a, b) in enumerate(pairs):
                 r = O.align(O.MODE_NAMES[mode], a, b, *sc)
                 assert int(res["score"][k]) == r["score"], (mode, sc, k, len(a), len(b))
@@ -730,3 +733,48 @@ def test_all_vs_all_scores_long_reads(al):
             positive += ref["score"] > 50
             t += 1
     assert positive >= 5       # real overlaps are in the set
+
+
+def test_bit_parallel_edit_distance(al):
+    """`edit -u 1` (unit mismatch cost: Levenshtein) runs on the bit-parallel kernel (at_myers.hip.h): every word / lane
+    boundary of l1 (32, 1024, 2048, 4096 rows), ragged and uniform batches, unrelated and related pairs, empty sequences,
+    against the oracle; any other -u keeps the cell-by-cell kernel."""
+    rng = random.Random(404)
+    dna = lambda n: "".join(rng.choice("ACGT") for _ in range(n))
+    def related(a):
+        t = list(a)
+        for _ in range(max(1, len(t) // 10)):
+            q = rng.randrange(len(t))
+            r = rng.random()
+            if r < 0.4:
+                t[q] = rng.choice("ACGT")
+            elif r < 0.7 and len(t) > 1:
+                del t[q]
+            else:
+                t.insert(q, rng.choice("ACGT"))
+        return "".join(t)
+    lens = [1, 2, 15, 16, 17, 31, 32, 33, 63, 64, 65, 100, 511, 512, 513, 1000, 1023, 1024, 1025, 1500, 2047, 2048, 2049, 3000, 4096, 4097, 5000, 8192]
+    ragged = []
+    for n in lens:
+        a = dna(n)
+        ragged.append((a, dna(rng.randint(1, min(2 * n + 5, 3000)))))
+        ragged.append((a, related(a)))
+        ragged.append((a, a))
+    ragged += [("", "ACGT"), ("ACG", ""), ("", "")]
+    al.set_scoring(1, 1, -5, -1)
+    res = al.align_batch("edit", ragged)
+    assert "myers" in al.last_config and "words/lane=8" in al.last_config, al.last_config
+    for k, (a, b) in enumerate(ragged):
+        assert int(res["score"][k]) == O.align(O.EDIT, a, b, 1, 1, -5, -1)["score"], (k, len(a), len(b))
+    for l1, l2, want in ((150, 150, 1), (1000, 1000, 1), (1024, 700, 1), (1025, 1100, 2), (33, 2000, 1)):
+        uniform = [(dna(l1), dna(l2)) if k % 2 else (lambda a: (a, (related(a) + dna(l2))[:l2]))(dna(l1)) for k in range(70)]
+        res = al.align_batch("edit", uniform)
+        assert "words/lane=%d" % want in al.last_config, al.last_config
+        for k, (a, b) in enumerate(uniform):
+            assert int(res["score"][k]) == O.align(O.EDIT, a, b, 1, 1, -5, -1)["score"], (l1, l2, k)
+    al.set_scoring(1, 2, -5, -1)          # another mismatch cost: the DP kernel
+    res = al.align_batch("edit", ragged[:20])
+    assert "int32" in al.last_config
+    al.set_scoring(1, 1, -5, -1)
+    res = al.align_batch("edit", [(dna(8193), dna(100))])          # longer than the bit-parallel kernel takes
+    assert "int32" in al.last_config

@@ -379,7 +379,7 @@ def main():
             "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "int16" if "packed16" in al.last_config else "int32", "data": "synthetic",
             "config": {"workload": "%s: %s %s, %d x (%dx%d bp) pairs per GPU, uniform ACGT, m=%d u=%d o=%d e=%d%s, "
-                                   "%s" % (args.workload, mode, "linear-gap" if mode == "overlap" else "affine-gap", pairs, l1, l2,
+                                   "%s" % (args.workload, mode, "linear-gap" if mode == "overlap" else "unit-gap" if mode == "edit" else "affine-gap", pairs, l1, l2,
                                            m, u, o, e, " j=%d -s" % j if uj else "",
                                            ("scores+tracebacks+rendered strings" if rend else "scores+tracebacks") if tb else "scores only"),
                        "pairs_per_gpu": pairs, "l1": l1, "l2": l2, "bits_per_base": bits, "kernel_config": al.last_config,

@@ -446,7 +446,8 @@ static int align_device(at_handle *h, int mode, int64_t npairs,
                         int32_t max_len1, int32_t max_len2, int uniform_shape, int want_traceback,
                         int32_t *d_score, int32_t *d_end_i, int32_t *d_end_j, int32_t *d_state,
                         uint8_t *d_ops, const int64_t *d_ops_off, int32_t *d_nops, void *stream_,
-                        int64_t ap_n, int64_t ap_first, const int *d_order = nullptr, int rag = 0);
+                        int64_t ap_n, int64_t ap_first, const int *d_order = nullptr, int rag = 0,
+                        const int *only_if = nullptr, int only_val = 0);
 
 extern "C" int at_align_batch_device(at_handle *h, int mode, int64_t npairs,
                                      const uint32_t *d_seq, int bits,
@@ -538,7 +539,7 @@ static int align_device(at_handle *h, int mode, int64_t npairs,
                         int32_t max_len1, int32_t max_len2, int uniform_shape, int want_traceback,
                         int32_t *d_score, int32_t *d_end_i, int32_t *d_end_j, int32_t *d_state,
                         uint8_t *d_ops, const int64_t *d_ops_off, int32_t *d_nops, void *stream_,
-                        int64_t ap_n, int64_t ap_first, const int *d_order, int rag)
+                        int64_t ap_n, int64_t ap_first, const int *d_order, int rag, const int *only_if, int only_val)
 {
 	if (!h) return fail(nullptr, AT_ERR_ARG, "at_align_batch_device: NULL handle");
 	if (mode < AT_MODE_GLOBAL || mode > AT_MODE_EDIT) return fail(h, AT_ERR_ARG, "unknown mode %d", mode);
@@ -568,6 +569,27 @@ static int align_device(at_handle *h, int mode, int64_t npairs,
 	/* ---- packed int16 path: uniform shape, scores provably within 16 bits ---- */
 	/* scores x16 with nibble pointers when they fit (|score| < 2048), else x4 with byte pointers (|score| < 8192) */
 	int thresh16 = 0, ts = 0;
+	if (!uniform_shape && !rag && !only_if && ap_n == 0 && npairs >= 4096 && !d_order && kmode <= at::K_FITJ &&
+	    env_ll("AT_AUTO_UNIFORM", 1) && packed_ok(h, mode, bits, max_len1, max_len2, 4, &thresh16)) {
+		/* The caller did not promise one shape, but the batch may well have one (fixed-length reads against fixed
+		 * windows).  The lengths live on the device and this entry is asynchronous, so the device decides: a check
+		 * kernel leaves 1 in a flag if every pair is max_len1 x max_len2, and the packed and the int32 launch are both
+		 * queued, each of them a no-op unless the flag names it. */
+		int *flag = h->d_rflag + 8;
+		HIP_TRY(h, hipMemsetAsync(flag, 0xff, 4, stream));
+		const unsigned cg = (unsigned)std::min<int64_t>((npairs + 255) / 256, 4LL * h->ncu);
+		hipLaunchKernelGGL(at::at_check_uniform, dim3(cg), dim3(256), 0, stream, d_len1, d_len2, (long long)npairs, max_len1, max_len2, flag);
+		int rc = align_device(h, mode, npairs, d_seq, bits, d_woff1, d_len1, d_woff2, d_len2, max_len1, max_len2, 1, want_traceback,
+		                      d_score, d_end_i, d_end_j, d_state, d_ops, d_ops_off, d_nops, stream_, 0, 0, nullptr, 0, flag, -1);
+		if (rc) return rc;
+		std::string packed_cfg = h->cfg;
+		rc = align_device(h, mode, npairs, d_seq, bits, d_woff1, d_len1, d_woff2, d_len2, max_len1, max_len2, 0, want_traceback,
+		                  d_score, d_end_i, d_end_j, d_state, d_ops, d_ops_off, d_nops, stream_, 0, 0, nullptr, 0, flag, 0);
+		if (rc) return rc;
+		snprintf(h->cfg, sizeof h->cfg, "auto: [%.140s] if every pair is %dx%d, else [%.120s]", packed_cfg.c_str(), max_len1, max_len2,
+		         std::string(h->cfg).c_str());
+		return AT_OK;
+	}
 	if ((uniform_shape || rag) && ap_n == 0) {
 		if (packed_ok(h, mode, bits, max_len1, max_len2, 4, &thresh16)) ts = 4;
 		else if (!rag && packed_ok(h, mode, bits, max_len1, max_len2, 2, &thresh16)) ts = 2;
@@ -600,6 +622,7 @@ static int align_device(at_handle *h, int mode, int64_t npairs,
 		b.score = d_score; b.end_i = d_end_i; b.end_j = d_end_j; b.state = d_state;
 		b.ops = d_ops; b.ops_off = (const long long *)d_ops_off; b.nops = d_nops;
 		b.order = rag ? d_order : nullptr;
+		b.only_if = only_if; b.only_val = only_val;
 		b.off_refb = P.off_refb; b.off_bound = P.off_bound; b.ptr_lanes = P.ptr_lanes; b.off_sm = P.off_sm; b.nsm = P.nsm;
 		Plan pl;
 		const int per_wave = 2 * (64 / P.g);
@@ -664,6 +687,7 @@ static int align_device(at_handle *h, int mode, int64_t npairs,
 	a.ops = d_ops; a.ops_off = (const long long *)d_ops_off; a.nops = d_nops;
 	a.off_bound = L.off_bound; a.ptr_lanes = L.ptr_lanes; a.off_sm = L.off_sm; a.nsm = L.nsm;
 	a.ap_n = ap_n; a.ap_first = ap_first; a.order = d_order;
+	a.only_if = only_if; a.only_val = only_val;
 	if (kmode == at::K_FITJ) {
 		int rc = ensure_sitemask(h, max_len2, stream);
 		if (rc) return rc;

@@ -60,4 +60,13 @@ __global__ __launch_bounds__(256) void at_pack(const PackArgs a)
 	}
 }
 
+/* *flag (preset to 1) becomes 0 unless every pair has exactly the lengths (l1, l2) */
+__global__ __launch_bounds__(256) void at_check_uniform(const int *len1, const int *len2, long long n, int l1, int l2, int *flag)
+{
+	int bad = 0;
+	for (long long k = (long long)blockIdx.x * blockDim.x + threadIdx.x; k < n; k += (long long)gridDim.x * blockDim.x)
+		bad |= len1[k] != l1 || len2[k] != l2;
+	if (__any(bad) && (threadIdx.x & 63) == 0) atomicAnd(flag, 0);
+}
+
 } /* namespace at */

@@ -84,6 +84,10 @@ struct SweepArgs {
 	long long ap_n, ap_first;
 	/* optional processing order (largest pairs first, so that ragged batches end without a long straggler) */
 	const int *order;
+	/* optional guard: the launch does nothing unless *only_if == only_val (at_align_batch_device queues the packed and
+	 * the int32 kernel behind a device-side check of the batch's shapes and lets the check decide) */
+	const int *only_if;
+	int only_val;
 };
 
 extern __shared__ uint32_t at_lds[];
@@ -278,6 +282,7 @@ __global__ __launch_bounds__(64) void at_sweep(const SweepArgs a)
 	uint32_t cM3 = 3u, cM7 = 7u;
 	asm volatile("" : "+v"(lut8), "+v"(e16v), "+v"(o16v), "+v"(g16v), "+v"(cM3), "+v"(cM7));
 
+	if (a.only_if && uni(*a.only_if) != a.only_val) return;
 	long long pnext = blockIdx.x;
 	while (pnext < a.npairs) {
 		const long long p = a.order ? (long long)a.order[pnext] : pnext;

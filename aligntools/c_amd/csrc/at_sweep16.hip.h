@@ -61,6 +61,8 @@ struct Sweep16Args {
 	/* RAG kernels (local, ragged batch): l1 / l2 are the FRAME every work item is swept in, len1 / len2 the pairs' own
 	 * extents (<= the frame); work item w takes pairs order[2*NG*w ...] (pairs of similar size, chosen by the host) */
 	const int *order;
+	const int *only_if;            /* optional guard, see SweepArgs */
+	int only_val;
 };
 
 AT_DEV uint32_t pk2(int v) { return ((uint32_t)v & 0xffffu) | ((uint32_t)v << 16); }
@@ -215,6 +217,7 @@ __global__ __launch_bounds__(64, AT_WAVES16(G, K)) void at_sweep16(const Sweep16
 	const long long nwork = (a.npairs + 2 * NG - 1) / (2 * NG);
 	const int refoff = grp * 2 * a.off_refb;  /* my group's two s2 byte arrays */
 
+	if (a.only_if && __builtin_amdgcn_readfirstlane(*a.only_if) != a.only_val) return;
 	long long wnext = blockIdx.x;
 	while (wnext < nwork) {
 		const long long wk = wnext;

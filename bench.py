@@ -97,6 +97,8 @@ def main():
     ap.add_argument("--bits", type=int, default=0, choices=[0, 2, 8],
                     help="sequence words: 0 = 2-bit when the batch is pure ACGT (it is), 8 = force byte words (the kernels for "
                          "reads with N / protein)")
+    ap.add_argument("--no-uniform-promise", action="store_true",
+                    help="call at_align_batch_device with uniform_shape = 0: the device checks the shapes itself (diagnostic)")
     ap.add_argument("--no-cigar-gather", action="store_true", help="N > 1: gather only the fixed-size results (diagnostic)")
     ap.add_argument("--no-gather", action="store_true", help="N > 1: no per-step collective at all (diagnostic)")
     ap.add_argument("--no-render", action="store_true",
@@ -221,7 +223,7 @@ def main():
                                      d_res[3].data_ptr(), None, None, None, stream)
         else:
             al.align_batch_device(A.MODES[mode], pairs, d_words.data_ptr(), bits, d_woff1.data_ptr(), d_len1.data_ptr(),
-                                  d_woff2.data_ptr(), d_len2.data_ptr(), l1, l2, True, tb,
+                                  d_woff2.data_ptr(), d_len2.data_ptr(), l1, l2, not args.no_uniform_promise, tb,
                                   d_res[0].data_ptr(), d_res[1].data_ptr(), d_res[2].data_ptr(), d_res[3].data_ptr(),
                                   d_ops.data_ptr() if tb else None, d_ops_off.data_ptr() if tb else None,
                                   d_res[4].data_ptr() if tb else None, stream)

@@ -290,7 +290,8 @@ def test_packed16_score_range_extremes(al, mode):
             if "packed16" not in al.last_config:                  # shape/scoring not admitted: nothing to test here
                 continue
             if (l1, l2) == (1024, 1024) and sc == (1, -1, -4, -1):
-                assert "packed16 x4" in al.last_config             # scores x4, byte pointers (at_sweep16 TS = 2)
+                # global / fit: scores x4 (at_sweep16 TS = 2); local has no downward drift and still fits x16
+                assert ("packed16 x16" if mode == "local" else "packed16 x4") in al.last_config
             for k, (s1, s2) in enumerate(pairs):
                 r = O.align(O.MODE_NAMES[mode], s1, s2, *sc)
                 assert r["rc"] == 0
@@ -814,3 +815,45 @@ def test_device_entry_detects_uniform_batches_itself(al):
                 ref = O.align(O.MODE_NAMES[mode], pairs[k][0], pairs[k][1], *sc)
                 got = (int(r[0, k]), int(r[1, k]), int(r[2, k]), int(r[3, k]), ops[k * (l1 + l2):k * (l1 + l2) + int(nops[k])].tobytes())
                 assert got == (ref["score"], ref["end_i"], ref["end_j"], ref["state"], ref["ops"]), (odd, mode, k)
+
+
+def test_local_packed_with_large_scores(al):
+    """Local matrices hold no -inf and do not drift downwards (M >= 0, L and U >= o), so the 16-bit range check of the
+    packed kernel only has to cover m * min(l1, l2): BLAST-like and minimap2-like scorings stay on the packed kernels."""
+    rng = random.Random(5150)
+    dna = lambda n: "".join(rng.choice("ACGT") for _ in range(n))
+    for sc, l1, l2 in (((5, -4, -10, -1), 150, 150), ((2, -8, -12, -2), 150, 160), ((2, -6, -5, -3), 100, 250), ((10, -9, -20, -5), 150, 150),
+                       ((1, -3, -5, -2), 1000, 1100)):
+        pairs = []
+        for k in range(80):
+            a = dna(l1)
+            if k % 2:
+                t = list(a)
+                for _ in range(l1 // 15):
+                    q = rng.randrange(len(t))
+                    r = rng.random()
+                    if r < 0.5:
+                        t[q] = rng.choice("ACGT")
+                    elif r < 0.75:
+                        del t[q]
+                    else:
+                        t.insert(q, rng.choice("ACGT"))
+                b = (dna(rng.randint(0, 20)) + "".join(t) + dna(l2))[:l2]
+            else:
+                b = dna(l2)
+            pairs.append((a, b))
+        al.set_scoring(*sc)
+        res = al.align_batch("local", pairs, render=False)
+        assert "packed16" in al.last_config, (sc, al.last_config)
+        for k, (a, b) in enumerate(pairs):
+            r = O.align(O.LOCAL, a, b, *sc)
+            assert (int(res["score"][k]), int(res["end_i"][k]), int(res["end_j"][k]), res["ops"][k]) == (r["score"], r["end_i"], r["end_j"], r["ops"]), (sc, k)
+    for sc, want in (((20, -30, -50, -10), "packed16 x4"),      # 20 * 150 * 16 > 2^15: scores x4 (and byte words: no byte LUT)
+                     ((200, -300, -500, -100), "int32")):        # 200 * 150 * 4 > 2^15: the int32 kernel
+        al.set_scoring(*sc)
+        pairs = [(dna(150), dna(150)) for _ in range(70)]
+        res = al.align_batch("local", pairs, render=False)
+        assert want in al.last_config, (sc, al.last_config)
+        for k, (a, b) in enumerate(pairs):
+            r = O.align(O.LOCAL, a, b, *sc)
+            assert (int(res["score"][k]), res["ops"][k]) == (r["score"], r["ops"]), (sc, k)

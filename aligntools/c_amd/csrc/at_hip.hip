@@ -327,7 +327,11 @@ static bool packed_ok(const at_handle *h, int mode, int bits, int l1, int l2, in
 	const bool hasj = mode == AT_MODE_FIT && h->use_jump;
 	if (hasj && (h->j > 0 || std::llabs((long long)h->j - h->o) * scale > 32000)) return false;
 	const long long A = std::max<long long>(std::max(std::llabs((long long)h->e), std::llabs((long long)h->u)), h->m);
-	long long lo = 3 * std::llabs((long long)h->o) + (hasj ? std::llabs((long long)h->j) : 0) + A * ((long long)l1 + l2) + 16;
+	/* global / fit: a cell's value is a max over paths, hence at least the value of one of them -- min(i, j) diagonal
+	 * steps, each >= u, and one gap of |i - j|, >= o + e * |i - j|; the L and U states lie at most one more opening below */
+	(void)A;
+	long long lo = 3 * std::llabs((long long)h->o) + (hasj ? std::llabs((long long)h->j) : 0) +
+	               std::llabs((long long)h->u) * std::min(l1, l2) + std::llabs((long long)h->e) * std::max(l1, l2) + 16;
 	/* local: M >= 0 everywhere (the 0 candidate, alignment.h:826), so L and U, each the max of something and M + o, never
 	 * drop below o, and no cell or intermediate below o + u + e: the matrix has no -inf and no downward drift */
 	if (mode == AT_MODE_LOCAL) lo = std::llabs((long long)h->o) + std::llabs((long long)h->u) + std::llabs((long long)h->e) + 16;

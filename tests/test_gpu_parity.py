@@ -857,3 +857,28 @@ def test_local_packed_with_large_scores(al):
         for k, (a, b) in enumerate(pairs):
             r = O.align(O.LOCAL, a, b, *sc)
             assert (int(res["score"][k]), res["ops"][k]) == (r["score"], r["ops"]), (sc, k)
+
+
+@pytest.mark.parametrize("mode", ["global", "fit"])
+def test_packed_range_check_harsh_mismatch(al, mode):
+    """Global / fit values are bounded below by |u| * min(l1, l2) + |e| * max(l1, l2) + openings (a max over paths is at least
+    one path): scorings with a harsh mismatch still fit the packed kernel's 16 bits.  Worst cases included: nothing matches,
+    one-sided gaps, everything matches."""
+    rng = random.Random(7788)
+    dna = lambda n: "".join(rng.choice("ACGT") for _ in range(n))
+    for sc, l1, l2 in (((2, -8, -12, -2), 150, 150), ((1, -9, -3, -1), 150, 170), ((3, -6, -8, -4), 120, 130), ((2, -8, -12, -2), 100, 250)):
+        if mode == "global" and l2 > 200:
+            continue
+        a = dna(l1)
+        pairs = [("A" * l1, "C" * l2), ("A" * l1, "A" * l2), (a, (a[l1 // 2:] + a)[:l2].ljust(l2, "T")), (a, ("G" * (l2 - l1) + a)[:l2]),
+                 ("AC" * (l1 // 2), ("CA" * l2)[:l2])]
+        pairs += [(dna(l1), dna(l2)) for _ in range(60)]
+        pairs = [(x[:l1].ljust(l1, "A"), y[:l2].ljust(l2, "C")) for x, y in pairs]
+        for uj in ((False, True) if mode == "fit" else (False,)):
+            al.set_scoring(*sc, -9, uj, [20, 60, 100])
+            res = al.align_batch(mode, pairs, render=False)
+            assert "packed16" in al.last_config, (sc, l1, l2, al.last_config)
+            for k, (x, y) in enumerate(pairs):
+                r = O.align(O.MODE_NAMES[mode], x, y, *sc, -9, uj, [20, 60, 100])
+                assert (int(res["score"][k]), int(res["end_i"][k]), int(res["end_j"][k]), int(res["state"][k]), res["ops"][k]) == \
+                       (r["score"], r["end_i"], r["end_j"], r["state"], r["ops"]), (mode, sc, uj, k)

@@ -567,8 +567,6 @@ static int align_device(at_handle *h, int mode, int64_t npairs,
 		return fail(h, AT_ERR_RANGE, "scores may exceed the exact range: max|param|=%lld, l1+l2=%lld", maxabs,
 		            (long long)max_len1 + max_len2);
 
-	if (bits == 2 && !scores_fit_byte(h, mode))
-		return fail(h, AT_ERR_RANGE, "2-bit kernels need |16*score| <= 127 (m=%d u=%d o=%d): pack the batch with bits=8", h->m, h->u, h->o);
 	const int kmode = mode == AT_MODE_GLOBAL ? at::K_GLOBAL : mode == AT_MODE_LOCAL ? at::K_LOCAL
 	                : mode == AT_MODE_FIT ? (h->use_jump ? at::K_FITJ : at::K_FIT)
 	                : mode == AT_MODE_OVERLAP ? at::K_OVERLAP : at::K_EDIT;
@@ -577,7 +575,8 @@ static int align_device(at_handle *h, int mode, int64_t npairs,
 	/* scores x16 with nibble pointers when they fit (|score| < 2048), else x4 with byte pointers (|score| < 8192) */
 	int thresh16 = 0, ts = 0;
 	if (!uniform_shape && !rag && !only_if && ap_n == 0 && npairs >= 4096 && !d_order && kmode <= at::K_FITJ &&
-	    env_ll("AT_AUTO_UNIFORM", 1) && packed_ok(h, mode, bits, max_len1, max_len2, 4, &thresh16)) {
+	    env_ll("AT_AUTO_UNIFORM", 1) && (bits == 8 || scores_fit_byte(h, mode)) &&
+	    packed_ok(h, mode, bits, max_len1, max_len2, 4, &thresh16)) {
 		/* The caller did not promise one shape, but the batch may well have one (fixed-length reads against fixed
 		 * windows).  The lengths live on the device and this entry is asynchronous, so the device decides: a check
 		 * kernel leaves 1 in a flag if every pair is max_len1 x max_len2, and the packed and the int32 launch are both
@@ -680,6 +679,9 @@ static int align_device(at_handle *h, int mode, int64_t npairs,
 		return AT_OK;
 	}
 
+	/* the int32 kernels read 2-bit scores from a byte LUT (the packed ones above from a 16-bit one) */
+	if (bits == 2 && !scores_fit_byte(h, mode))
+		return fail(h, AT_ERR_RANGE, "the int32 2-bit kernels need |16*score| <= 127 (m=%d u=%d o=%d): pack the batch with bits=8", h->m, h->u, h->o);
 	const Layout L = layout_for(kmode, bits, tb, max_len1, max_len2);
 	if (L.words >= (1LL << 30)) return fail(h, AT_ERR_RANGE, "pair too large: %lld workspace words", L.words);
 	SweepArgs a;

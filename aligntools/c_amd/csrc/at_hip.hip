@@ -283,7 +283,8 @@ struct Layout16 {
 };
 
 /* Group width: reads of 49..208 bases run as 4 groups of 16 lanes x K rows (8 alignments per wave, 85 % of the
- * lane-steps inside a 150 x 150 matrix instead of 59 %); everything else as one group of 64 lanes. */
+ * lane-steps inside a 150 x 150 matrix instead of 59 %), reads of 209..416 bases as 2 groups of 32 lanes, everything
+ * else as one group of 64 lanes. */
 static Layout16 layout16_for(bool tb, bool hasj, int l1, int l2, int ts, bool force16 = false)
 {
 	Layout16 L;
@@ -293,6 +294,11 @@ static Layout16 layout16_for(bool tb, bool hasj, int l1, int l2, int ts, bool fo
 	if ((force16 || (g_forced != 64 && l1 > 48)) && ts == 4 && l1 <= 208) {
 		L.g = 16;
 		L.k = l1 <= 64 ? 4 : l1 <= 80 ? 5 : l1 <= 96 ? 6 : l1 <= 112 ? 7 : (l1 <= 160 ? 10 : 13);
+	} else if (g_forced != 64 && ts == 4 && l1 > 208 && l1 <= 416) {
+		/* 250- and 300-base reads: two groups of 32 lanes (4 alignments per wave); one group of 64 lanes would carry 2 and
+		 * cut 300 rows into a strip of 256 and one of 44 */
+		L.g = 32;
+		L.k = l1 <= 224 ? 7 : l1 <= 256 ? 8 : l1 <= 320 ? 10 : 13;
 	}
 	const int ng = 64 / L.g;
 	const int blk = L.g == 16 ? 4 : 8;        /* BLK of at_sweep16 */

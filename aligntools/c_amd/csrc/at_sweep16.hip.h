@@ -133,7 +133,7 @@ AT_DEV int sat16(int v) { return v < -32768 ? -32768 : (v > 32767 ? 32767 : v); 
 
 /* second __launch_bounds__ argument = waves per SIMD the register allocator must leave room for */
 #ifndef AT_WAVES16
-#define AT_WAVES16(G, K) ((G) == 16 && (K) >= 10 ? 3 : 1)
+#define AT_WAVES16(G, K) (((G) == 16 || (G) == 32) && (K) >= 10 ? 3 : 1)
 #endif
 
 /* shift up by one lane inside a group of G lanes; lane 0 of each group keeps `old` */
@@ -141,6 +141,11 @@ template <int G>
 AT_DEV uint32_t grp_up1(uint32_t old, uint32_t src)
 {
 	if constexpr (G == 64) return (uint32_t)__builtin_amdgcn_update_dpp((int)old, (int)src, 0x138 /* wave_shr:1 */, 0xf, 0xf, false);
+	else if constexpr (G == 32) {
+		/* two DPP rows per group: shift across the whole wave, then give lane 32 (lane 0 of the second group) its own `old` */
+		const uint32_t v = (uint32_t)__builtin_amdgcn_update_dpp((int)old, (int)src, 0x138 /* wave_shr:1 */, 0xf, 0xf, false);
+		return threadIdx.x == 32 ? old : v;
+	}
 	else return (uint32_t)__builtin_amdgcn_update_dpp((int)old, (int)src, 0x111 /* row_shr:1 */, 0xf, 0xf, false);
 }
 
@@ -174,7 +179,7 @@ __global__ __launch_bounds__(64, AT_WAVES16(G, K)) void at_sweep16(const Sweep16
 	constexpr int TGL = TB ? OTGL : 0, TGM = TB ? OTGM : 0, TGU = TB ? OTGU : 0;
 	constexpr int PB = HASJ ? 8 : 4;          /* pointer bits per cell and alignment */
 	constexpr int SPW = 16 / PB;              /* steps per pointer word (each half holds its own alignment) */
-	static_assert(G == 64 || G == 16, "group width");
+	static_assert(G == 64 || G == 32 || G == 16, "group width");
 	constexpr int NG = 64 / G;                /* groups per wavefront, 2 alignments each */
 	/* steps per unrolled block.  The 16-lane kernels carry 7..13 rows per lane, so 4 steps (one pointer word) already
 	 * unroll to ~6 KB of code and only one (masked) body is emitted: every launch starts with a cold instruction

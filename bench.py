@@ -97,6 +97,8 @@ def main():
     ap.add_argument("--bits", type=int, default=0, choices=[0, 2, 8],
                     help="sequence words: 0 = 2-bit when the batch is pure ACGT (it is), 8 = force byte words (the kernels for "
                          "reads with N / protein)")
+    ap.add_argument("--l1", type=int, default=0, help="override the workload's first length (diagnostic)")
+    ap.add_argument("--l2", type=int, default=0, help="override the workload's second length (diagnostic)")
     ap.add_argument("--no-uniform-promise", action="store_true",
                     help="call at_align_batch_device with uniform_shape = 0: the device checks the shapes itself (diagnostic)")
     ap.add_argument("--no-cigar-gather", action="store_true", help="N > 1: gather only the fixed-size results (diagnostic)")
@@ -117,6 +119,7 @@ def main():
     mode, l1, l2, pairs, scoring, use_jump, sites, seed = WORKLOADS[args.workload]
     if args.pairs:
         pairs = args.pairs
+    l1, l2 = args.l1 or l1, args.l2 or l2
 
     # CPU baseline first (child process, before this process touches the GPU)
     base = None

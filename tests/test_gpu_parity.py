@@ -882,3 +882,42 @@ def test_packed_range_check_harsh_mismatch(al, mode):
                 r = O.align(O.MODE_NAMES[mode], x, y, *sc, -9, uj, [20, 60, 100])
                 assert (int(res["score"][k]), int(res["end_i"][k]), int(res["end_j"][k]), int(res["state"][k]), res["ops"][k]) == \
                        (r["score"], r["end_i"], r["end_j"], r["state"], r["ops"]), (mode, sc, uj, k)
+
+
+@pytest.mark.parametrize("mode", ["local", "global", "fit", "fitj"])
+def test_packed_32_lane_groups(al, mode):
+    """Reads of 209..416 bases (250- and 300-base reads) run as two groups of 32 lanes, 7 / 8 / 10 / 13 rows per lane: every
+    class edge, both alphabets, related and unrelated pairs, against the oracle."""
+    rng = random.Random(3232)
+    uj = mode == "fitj"
+    m = "fit" if uj else mode
+    for l1, l2, alpha in ((209, 209, "ACGT"), (224, 260, "ACGT"), (225, 225, "ACGTN"), (250, 250, "ACGT"), (256, 300, "ACGT"), (257, 257, "ACGT"),
+                          (300, 300, "ACGT"), (320, 400, "ACGTN"), (321, 321, "ACGT"), (416, 416, "ACGT")):
+        pairs = []
+        for k in range(24):
+            a = "".join(rng.choice(alpha) for _ in range(l1))
+            if k % 2:
+                t = list(a)
+                for _ in range(l1 // 18):
+                    q = rng.randrange(len(t))
+                    r = rng.random()
+                    if r < 0.5:
+                        t[q] = rng.choice(alpha)
+                    elif r < 0.75:
+                        del t[q]
+                    else:
+                        t.insert(q, rng.choice(alpha))
+                b = ("".join(rng.choice(alpha) for _ in range(rng.randint(0, 25))) + "".join(t) + "".join(rng.choice(alpha) for _ in range(l2)))[:l2]
+            else:
+                b = "".join(rng.choice(alpha) for _ in range(l2))
+            pairs.append((a, b))
+        sc = (2, -2, -5, -2, -9) if mode != "global" else (1, -2, -4, -1, -9)
+        al.set_scoring(*sc, uj, [50, 150, 250])
+        res = al.align_batch(m, pairs, render=False)
+        assert "packed16" in al.last_config, (l1, l2, al.last_config)
+        if "packed16 x16" in al.last_config:      # (scores x4 when x16 would leave 16 bits: one 64-lane group)
+            assert "2x32-lane groups" in al.last_config, (l1, l2, al.last_config)
+        for k, (x, y) in enumerate(pairs):
+            r = O.align(O.MODE_NAMES[m], x, y, *sc, uj, [50, 150, 250])
+            assert (int(res["score"][k]), int(res["end_i"][k]), int(res["end_j"][k]), int(res["state"][k]), res["ops"][k]) == \
+                   (r["score"], r["end_i"], r["end_j"], r["state"], r["ops"]), (mode, l1, l2, k)

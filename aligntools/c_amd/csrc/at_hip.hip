@@ -282,7 +282,7 @@ struct Layout16 {
 	long long words;
 };
 
-/* Group width: reads of 49..208 bases run as 4 groups of 16 lanes x K rows (8 alignments per wave, 85 % of the
+/* Group width: reads of up to 208 bases run as 4 groups of 16 lanes x K rows (8 alignments per wave, 85 % of the
  * lane-steps inside a 150 x 150 matrix instead of 59 %), reads of 209..416 bases as 2 groups of 32 lanes, everything
  * else as one group of 64 lanes. */
 static Layout16 layout16_for(bool tb, bool hasj, int l1, int l2, int ts, bool force16 = false)
@@ -291,7 +291,7 @@ static Layout16 layout16_for(bool tb, bool hasj, int l1, int l2, int ts, bool fo
 	const long long g_forced = env_ll("AT_GROUP", 0);
 	L.g = 64;
 	L.k = rows_per_lane(l1);
-	if ((force16 || (g_forced != 64 && l1 > 48)) && ts == 4 && l1 <= 208) {
+	if ((force16 || g_forced != 64) && ts == 4 && l1 <= 208) {
 		L.g = 16;
 		L.k = l1 <= 64 ? 4 : l1 <= 80 ? 5 : l1 <= 96 ? 6 : l1 <= 112 ? 7 : (l1 <= 160 ? 10 : 13);
 	} else if (g_forced != 64 && ts == 4 && l1 > 208 && l1 <= 416) {
@@ -399,7 +399,8 @@ struct Plan {
 };
 
 static int plan_launch(at_handle *h, const char *tag, int k, long long nwork, long long words_fixed, long long words_ptr,
-                       Plan *pl, hipStream_t stream, const std::function<const void *(int)> &kernel_for_store)
+                       Plan *pl, hipStream_t stream, const std::function<const void *(int)> &kernel_for_store,
+                       bool prefer_hbm_pointers = false)
 {
 	/* all-LDS only while at least 8 waves (2 per SIMD) still fit a CU: measured, occupancy beyond 1 wave/SIMD is
 	 * worth +30..50 % on this issue-bound kernel (profiles/r01) */
@@ -411,6 +412,9 @@ static int plan_launch(at_handle *h, const char *tag, int k, long long nwork, lo
 	else if ((words_fixed + words_ptr) * 4 <= limit_all) store = 0;
 	else if (words_fixed * 4 <= limit_fixed) store = 1;
 	else store = 2;
+	/* several alignments per wave (16- and 32-lane groups): the pointer matrices in LDS would cap the CU at a few waves
+	 * even when they fit (49-base reads: 1 151 GCUPS all-LDS, 1 357 with the slots in HBM) */
+	if (prefer_hbm_pointers && forced < 0 && store == 0 && words_ptr > 0) store = 1;
 	if (words_ptr == 0 && store == 1) store = 0;
 	if (store < 2 && words_fixed * 4 > 150 * 1024) store = 2;
 	if (store == 0 && (words_fixed + words_ptr) * 4 > 150 * 1024) store = 1;
@@ -643,7 +647,7 @@ static int align_device(at_handle *h, int mode, int64_t npairs,
 		         rag ? " ragged frames" : "");
 		auto pick = [&](int st) { return rag ? at_pick16_rag(P.k, st, tb, bits) : at_pick16(kmode, P.g, P.k, ts, st, tb, bits); };
 		int rc = plan_launch(h, tag16, P.k, (npairs + per_wave - 1) / per_wave, P.off_ptr, P.words - P.off_ptr, &pl, stream,
-		                     [&](int st) { return (const void *)pick(st); });
+		                     [&](int st) { return (const void *)pick(st); }, P.g < 64);
 		if (rc) return rc;
 		b.off_ptr = pl.off_ptr; b.ws = pl.ws; b.ws_slot_words = pl.slot_words; b.queue = h->d_queue;
 		at_sweep16_fn fn16 = pick(pl.store);

@@ -348,6 +348,15 @@ static bool packed_ok(const at_handle *h, int mode, int bits, int l1, int l2, in
 	return true;
 }
 
+static int choose_store(long long words_fixed, long long words_ptr, bool prefer_hbm_pointers);
+/* is there a packed instantiation for the storage class plan_launch will choose for this layout? */
+static bool packed16_kernel_exists(int kmode, const Layout16 &P, bool tb, int ts, int bits, bool rag)
+{
+	const int st = choose_store(P.off_ptr, P.words - P.off_ptr, P.g < 64);
+	if (P.g != 64 && st == 2) return false;
+	return (rag ? at_pick16_rag(P.k, st, tb, bits) : at_pick16(kmode, P.g, P.k, ts, st, tb, bits)) != nullptr;
+}
+
 static int grow(at_handle *h, void **p, size_t *have, size_t need)
 {
 	if (need <= *have) return AT_OK;
@@ -398,9 +407,8 @@ struct Plan {
 	uint32_t *ws;
 };
 
-static int plan_launch(at_handle *h, const char *tag, int k, long long nwork, long long words_fixed, long long words_ptr,
-                       Plan *pl, hipStream_t stream, const std::function<const void *(int)> &kernel_for_store,
-                       bool prefer_hbm_pointers = false)
+/* storage class for (fixed, pointer) words per work item; no side effects (also used to ask whether a kernel exists) */
+static int choose_store(long long words_fixed, long long words_ptr, bool prefer_hbm_pointers)
 {
 	/* all-LDS only while at least 8 waves (2 per SIMD) still fit a CU: measured, occupancy beyond 1 wave/SIMD is
 	 * worth +30..50 % on this issue-bound kernel (profiles/r01) */
@@ -418,6 +426,14 @@ static int plan_launch(at_handle *h, const char *tag, int k, long long nwork, lo
 	if (words_ptr == 0 && store == 1) store = 0;
 	if (store < 2 && words_fixed * 4 > 150 * 1024) store = 2;
 	if (store == 0 && (words_fixed + words_ptr) * 4 > 150 * 1024) store = 1;
+	return store;
+}
+
+static int plan_launch(at_handle *h, const char *tag, int k, long long nwork, long long words_fixed, long long words_ptr,
+                       Plan *pl, hipStream_t stream, const std::function<const void *(int)> &kernel_for_store,
+                       bool prefer_hbm_pointers = false)
+{
+	const int store = choose_store(words_fixed, words_ptr, prefer_hbm_pointers);
 	const long long lds_words = store == 0 ? words_fixed + words_ptr : (store == 1 ? words_fixed : 0);
 	const long long slot_words = store == 0 ? 0 : (((store == 1 ? words_ptr : words_fixed + words_ptr) + 63) & ~63LL);
 	long long per_cu = 16;
@@ -521,6 +537,19 @@ extern "C" int at_render_batch_device(at_handle *h, int64_t npairs,
 	return AT_OK;
 }
 
+/* exclusive prefix sums of max(nops, 0) into d_off[0 .. npairs] (d_off[npairs] = total) */
+static int scan_nops_device(at_handle *h, int64_t npairs, const int32_t *d_nops, int64_t *d_off, hipStream_t s)
+{
+	const unsigned ntiles = (unsigned)((npairs + at::SCAN_TILE - 1) / at::SCAN_TILE);
+	int rc = grow(h, &h->d_scan, &h->scan_bytes, (size_t)ntiles * 8);
+	if (rc) return rc;
+	hipLaunchKernelGGL(at::at_scan_tiles, dim3(ntiles), dim3(256), 0, s, d_nops, (long long)npairs, (long long *)h->d_scan);
+	hipLaunchKernelGGL(at::at_scan_nops, dim3(ntiles), dim3(256), 0, s, d_nops, (long long)npairs, (const long long *)h->d_scan,
+	                   (long long *)d_off);
+	HIP_TRY(h, hipGetLastError());
+	return AT_OK;
+}
+
 extern "C" int at_compact_ops_device(at_handle *h, int64_t npairs,
                                      const uint8_t *d_ops, const int64_t *d_ops_off, const int32_t *d_nops,
                                      uint8_t *d_packed, int64_t packed_cap, int64_t *d_packed_off, void *stream_)
@@ -534,12 +563,8 @@ extern "C" int at_compact_ops_device(at_handle *h, int64_t npairs,
 		HIP_TRY(h, hipMemsetAsync(d_packed_off, 0, 8, s));
 		return AT_OK;
 	}
-	const unsigned ntiles = (unsigned)((npairs + at::SCAN_TILE - 1) / at::SCAN_TILE);
-	int rc = grow(h, &h->d_scan, &h->scan_bytes, (size_t)ntiles * 8);
+	int rc = scan_nops_device(h, npairs, d_nops, d_packed_off, s);
 	if (rc) return rc;
-	hipLaunchKernelGGL(at::at_scan_tiles, dim3(ntiles), dim3(256), 0, s, d_nops, (long long)npairs, (long long *)h->d_scan);
-	hipLaunchKernelGGL(at::at_scan_nops, dim3(ntiles), dim3(256), 0, s, d_nops, (long long)npairs, (const long long *)h->d_scan,
-	                   (long long *)d_packed_off);
 	{
 		const unsigned grid = (unsigned)std::min<int64_t>((npairs + 15) / 16, 16LL * h->ncu);
 		hipLaunchKernelGGL(at::at_compact_k, dim3(grid), dim3(256), 0, s, (long long)npairs, d_ops, (const long long *)d_ops_off,
@@ -620,6 +645,12 @@ static int align_device(at_handle *h, int mode, int64_t npairs,
 		 * packed vs 2.00 TCUPS int32 for a lone launch, 2.70 vs 2.13 with launches in flight; 61k pairs: 2.70 vs 2.19.) */
 		const double min_rounds = getenv("AT_PACKED_MIN_ROUNDS") ? atof(getenv("AT_PACKED_MIN_ROUNDS")) : 1.0;
 		if (P.g == 64 && (double)((npairs + 1) / 2) < min_rounds * 12.0 * h->ncu) ts = 0;
+		/* no packed kernel for the storage class this shape needs (the 16- and 32-lane groups have no all-HBM variant:
+		 * a 150-base read against a second sequence of more than ~4 000 bases): the int32 kernel takes any length */
+		if (ts && !packed16_kernel_exists(kmode, P, tb, ts, bits, rag != 0)) {
+			if (rag) return fail(h, AT_ERR_ARG, "ragged packed launch outside its domain (frame too long for LDS)");
+			ts = 0;
+		}
 	}
 	if (ts) {
 		Sweep16Args b;
@@ -651,7 +682,7 @@ static int align_device(at_handle *h, int mode, int64_t npairs,
 		if (rc) return rc;
 		b.off_ptr = pl.off_ptr; b.ws = pl.ws; b.ws_slot_words = pl.slot_words; b.queue = h->d_queue;
 		at_sweep16_fn fn16 = pick(pl.store);
-		if (!fn16 || (P.g == 16 && pl.store == 2)) return fail(h, AT_ERR_RANGE, "no packed kernel for this shape (rows/lane=%d, store=%d)", P.k, pl.store);
+		if (!fn16 || (P.g != 64 && pl.store == 2)) return fail(h, AT_ERR_RANGE, "no packed kernel for this shape (rows/lane=%d, store=%d)", P.k, pl.store);
 		if (pl.dyn_lds > 48 * 1024)
 			HIP_TRY(h, hipFuncSetAttribute((const void *)fn16, hipFuncAttributeMaxDynamicSharedMemorySize, (int)pl.dyn_lds));
 		hipLaunchKernelGGL(fn16, dim3((unsigned)pl.grid), dim3(64), pl.dyn_lds, stream, b);
@@ -749,7 +780,7 @@ static int align_host(at_handle *h, int mode, int64_t npairs, const uint8_t *seq
 
 	int max1 = 0, max2 = 0;
 	bool uniform = true;
-	int64_t ops_total = 0, ops_lo = INT64_MAX, blob_lo = INT64_MAX;
+	int64_t ops_total = 0, ops_lo = INT64_MAX, blob_lo = INT64_MAX, slots_total = 0;
 	for (int64_t k = 0; k < npairs; ++k) {
 		if (len1[k] < 0 || len2[k] < 0) return fail(h, AT_ERR_ARG, "pair %lld: negative length", (long long)(pair_base + k));
 		/* the domain on which the reference is defined (last paragraph) */
@@ -764,6 +795,7 @@ static int align_host(at_handle *h, int mode, int64_t npairs, const uint8_t *seq
 			if (ops_off[k] < 0) return fail(h, AT_ERR_ARG, "pair %lld: negative ops offset", (long long)(pair_base + k));
 			ops_total = std::max<int64_t>(ops_total, ops_off[k] + len1[k] + len2[k] + (strings ? 1 : 0));
 			ops_lo = std::min<int64_t>(ops_lo, ops_off[k]);
+			slots_total += (int64_t)len1[k] + len2[k];
 		}
 		if (off1[k] < 0 || off2[k] < 0) return fail(h, AT_ERR_ARG, "pair %lld: negative sequence offset", (long long)(pair_base + k));
 		blob_lo = std::min<int64_t>(blob_lo, std::min(off1[k], off2[k]));
@@ -853,13 +885,15 @@ static int align_host(at_handle *h, int mode, int64_t npairs, const uint8_t *seq
 	HIP_TRY(h, hipStreamSynchronize(s));   /* woff1/woff2 are stack-lifetime vectors */
 	const size_t b_len1 = al((size_t)npairs * 4);
 	/* device output block: score | end_i | end_j | state | nops | ops */
-	const size_t out_need = 5 * b_len1 + al((size_t)ops_total + 64);
+	const size_t b_ops = al((size_t)ops_total + 64), b_pfx = al((size_t)(npairs + 1) * 8);
+	const size_t out_need = 5 * b_len1 + b_ops + (tb ? b_pfx : 0);
 	rc = grow(h, &h->d_out, &h->out_bytes, out_need);
 	if (rc) return rc;
 	char *dout = (char *)h->d_out;
 	int32_t *d_score = (int32_t *)dout, *d_ei = (int32_t *)(dout + b_len1), *d_ej = (int32_t *)(dout + 2 * b_len1);
 	int32_t *d_st = (int32_t *)(dout + 3 * b_len1), *d_nops = (int32_t *)(dout + 4 * b_len1);
 	uint8_t *d_ops = (uint8_t *)(dout + 5 * b_len1);
+	int64_t *d_poff = (int64_t *)(dout + 5 * b_len1 + b_ops);   /* exclusive prefix sums of nops (tb only) */
 
 	/* ragged batch.  Local alignments of reads (l1 <= 208, 2-bit, scores within 16 bits) go to the packed kernel in
 	 * FRAMES: pairs are sorted by (rows-per-lane class of l1, l2), cut into buckets of similar size, and every bucket is
@@ -875,6 +909,8 @@ static int align_host(at_handle *h, int mode, int64_t npairs, const uint8_t *seq
 		int th = 0;
 		frames = mode == AT_MODE_LOCAL && max1 <= 208 && npairs >= 64 && env_ll("AT_RAGGED_PACKED", 1) &&
 		         packed_ok(h, mode, bits, max1, max2, 4, &th);
+		/* every frame is at most max1 x max2: if that one has no packed kernel (s2 too long for LDS), none is tried */
+		if (frames) frames = packed16_kernel_exists(at::K_LOCAL, layout16_for(tb, false, max1, max2, 4, true), tb, 4, bits, true);
 		auto kclass = [](int l1) { return l1 <= 64 ? 4 : l1 <= 80 ? 5 : l1 <= 96 ? 6 : l1 <= 112 ? 7 : l1 <= 160 ? 10 : 13; };
 		if (frames) {
 			/* (class descending, l2 descending, index ascending): a counting sort -- the key space is 6 x (max2 + 1) */
@@ -927,28 +963,61 @@ static int align_host(at_handle *h, int mode, int64_t npairs, const uint8_t *seq
 	if (out_end_i) HIP_TRY(h, hipMemcpyAsync(out_end_i, d_ei, (size_t)npairs * 4, hipMemcpyDeviceToHost, s));
 	if (out_end_j) HIP_TRY(h, hipMemcpyAsync(out_end_j, d_ej, (size_t)npairs * 4, hipMemcpyDeviceToHost, s));
 	if (out_state) HIP_TRY(h, hipMemcpyAsync(out_state, d_st, (size_t)npairs * 4, hipMemcpyDeviceToHost, s));
+	/* Only the bytes of each pair's own result travel and are written: the used part of every ops slot (or string
+	 * slot) is packed back to back on the GPU, copied down in one piece and scattered into the caller's slots here.
+	 * Bytes of the caller's buffers between and behind the slots are never touched, whatever order the slots are in. */
 	int rflag = 0;
+	std::vector<int64_t> h_poff;
+	uint8_t *d_pk1 = nullptr, *d_pk2 = nullptr;
 	if (tb) {
 		HIP_TRY(h, hipMemcpyAsync(out_nops, d_nops, (size_t)npairs * 4, hipMemcpyDeviceToHost, s));
-		if (out_ops) HIP_TRY(h, hipMemcpyAsync(out_ops + ops_lo, d_ops, (size_t)ops_total, hipMemcpyDeviceToHost, s));
-		if (strings) {
-			const size_t b_str = al((size_t)ops_total + 64);
-			rc = grow(h, &h->d_str, &h->str_bytes, 2 * b_str);
+		const size_t b_str = al((size_t)slots_total + (size_t)npairs + 64);
+		rc = grow(h, &h->d_str, &h->str_bytes, (strings ? 2 : 1) * b_str + (strings ? b_pfx : 0));
+		if (rc) return rc;
+		d_pk1 = (uint8_t *)h->d_str; d_pk2 = d_pk1 + b_str;
+		if (!strings) {
+			rc = at_compact_ops_device(h, npairs, d_ops, d_opsoff, d_nops, d_pk1, slots_total, d_poff, s);
 			if (rc) return rc;
-			uint8_t *d_r1 = (uint8_t *)h->d_str, *d_r2 = d_r1 + b_str;
+		} else {
+			rc = scan_nops_device(h, npairs, d_nops, d_poff, s);
+			if (rc) return rc;
+			int64_t *d_stroff = (int64_t *)(d_pk1 + 2 * b_str);   /* string k starts at poff[k] + k: one NUL behind each */
+			hipLaunchKernelGGL(at::at_add_index, dim3((unsigned)std::min<int64_t>((npairs + 255) / 256, 8LL * h->ncu)), dim3(256), 0, s,
+			                   (const long long *)d_poff, (long long *)d_stroff, (long long)npairs);
 			HIP_TRY(h, hipMemsetAsync(h->d_rflag, 0, 4, s));
 			rc = at_render_batch_device(h, npairs, d_words, bits, d_woff1, d_woff2, d_ei, d_ej, d_ops, d_opsoff, d_nops,
-			                            d_r1, d_r2, nullptr, 1, s);
+			                            d_pk1, d_pk2, d_stroff, 1, s);
 			if (rc) return rc;
-			HIP_TRY(h, hipMemcpyAsync(out_r1 + ops_lo, d_r1, (size_t)ops_total, hipMemcpyDeviceToHost, s));
-			HIP_TRY(h, hipMemcpyAsync(out_r2 + ops_lo, d_r2, (size_t)ops_total, hipMemcpyDeviceToHost, s));
 			HIP_TRY(h, hipMemcpyAsync(&rflag, h->d_rflag, 4, hipMemcpyDeviceToHost, s));
 		}
+		h_poff.resize((size_t)npairs + 1);
+		HIP_TRY(h, hipMemcpyAsync(h_poff.data(), d_poff, (size_t)(npairs + 1) * 8, hipMemcpyDeviceToHost, s));
 	}
 	HIP_TRY(h, hipStreamSynchronize(s));
 	for (int64_t k = 0; k < npairs; ++k) {
 		if (out_score[k] == INT32_MIN || (tb && out_nops[k] < 0))
 			return fail(h, AT_ERR_DOMAIN, "pair %lld: input outside the domain on which the reference is defined", (long long)(pair_base + k));
+	}
+	if (tb) {
+		const int64_t total = h_poff[(size_t)npairs];
+		if (total < 0 || total > slots_total) return fail(h, AT_ERR_DOMAIN, "traceback lengths inconsistent with the slots");
+		if (!strings) {
+			std::vector<uint8_t> pk((size_t)total + 1);
+			if (total) HIP_TRY(h, hipMemcpyAsync(pk.data(), d_pk1, (size_t)total, hipMemcpyDeviceToHost, s));
+			HIP_TRY(h, hipStreamSynchronize(s));
+			for (int64_t k = 0; k < npairs; ++k)
+				if (out_nops[k] > 0) memcpy(out_ops + ops_off[k], pk.data() + h_poff[(size_t)k], (size_t)out_nops[k]);
+		} else {
+			std::vector<char> p1((size_t)(total + npairs) + 1), p2((size_t)(total + npairs) + 1);
+			HIP_TRY(h, hipMemcpyAsync(p1.data(), d_pk1, (size_t)(total + npairs), hipMemcpyDeviceToHost, s));
+			HIP_TRY(h, hipMemcpyAsync(p2.data(), d_pk2, (size_t)(total + npairs), hipMemcpyDeviceToHost, s));
+			HIP_TRY(h, hipStreamSynchronize(s));
+			for (int64_t k = 0; k < npairs; ++k) {
+				const size_t src = (size_t)(h_poff[(size_t)k] + k), n = (size_t)out_nops[k] + 1;   /* with the NUL */
+				memcpy(out_r1 + ops_off[k], p1.data() + src, n);
+				memcpy(out_r2 + ops_off[k], p2.data() + src, n);
+			}
+		}
 	}
 	if (rflag) return fail(h, AT_ERR_DOMAIN, "traceback inconsistent with its sequences");
 	return AT_OK;

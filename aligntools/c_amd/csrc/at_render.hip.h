@@ -160,4 +160,10 @@ __global__ __launch_bounds__(256) void at_compact_k(long long npairs, const uint
 	}
 }
 
+/* dst[k] = src[k] + k: where string k starts when every packed string is followed by one NUL */
+__global__ __launch_bounds__(256) void at_add_index(const long long *src, long long *dst, long long n)
+{
+	for (long long k = (long long)blockIdx.x * blockDim.x + threadIdx.x; k < n; k += (long long)gridDim.x * blockDim.x) dst[k] = src[k] + k;
+}
+
 } /* namespace at */

@@ -11,8 +11,6 @@ import torch.distributed as dist
 
 from . import opt_t, MODES, MODE_EDIT
 
-_MAX_SITES = 256
-
 
 def shard_range(n, rank, world):
     """Contiguous range [lo, hi) of pair indices owned by `rank` (pair k -> rank floor(k*world/n))."""
@@ -26,16 +24,24 @@ def _dev():
 
 
 def broadcast_scoring(opt, src=0):
-    """Rank `src` owns the scoring block; every rank returns an identical opt_t."""
+    """Rank `src` owns the scoring block; every rank returns an identical opt_t.  Two broadcasts: the fixed block
+    (m,u,o,e,j, use_jump, number of sites), then a tensor of exactly that many junction sites -- the reference's site
+    list has no upper bound (alignment.h:243-256), so neither has this."""
     dev = _dev()
-    buf = torch.zeros(8 + _MAX_SITES, dtype=torch.int32, device=dev)
+    head = torch.zeros(8, dtype=torch.int32, device=dev)
+    sites = [int(x) for x in opt.sites] if dist.get_rank() == src else []
     if dist.get_rank() == src:
-        sites = list(opt.sites)[:_MAX_SITES]
-        vals = [opt.m, opt.u, opt.o, opt.e, opt.j, 1 if opt.s else 0, len(sites), 0] + sites
-        buf[: len(vals)] = torch.tensor(vals, dtype=torch.int32, device=dev)
-    dist.broadcast(buf, src=src)
-    v = buf.cpu().tolist()
-    return opt_t(m=v[0], u=v[1], o=v[2], e=v[3], j=v[4], s=bool(v[5]), sites=v[8:8 + v[6]])
+        head[:7] = torch.tensor([opt.m, opt.u, opt.o, opt.e, opt.j, 1 if opt.s else 0, len(sites)], dtype=torch.int32, device=dev)
+    dist.broadcast(head, src=src)
+    v = head.cpu().tolist()
+    ns = v[6]
+    if ns > 0:
+        sbuf = torch.zeros(ns, dtype=torch.int32, device=dev)
+        if dist.get_rank() == src:
+            sbuf[:] = torch.tensor(sites, dtype=torch.int32, device=dev)
+        dist.broadcast(sbuf, src=src)
+        sites = sbuf.cpu().tolist()
+    return opt_t(m=v[0], u=v[1], o=v[2], e=v[3], j=v[4], s=bool(v[5]), sites=sites)
 
 
 def gather_results(local, n_total):

@@ -147,24 +147,31 @@ def main():
             dist.init_process_group("gloo", rank=rank, world_size=world)
 
     # ---- scoring block: rank 0 owns it, RCCL broadcast to the other ranks ----
-    sc = torch.tensor(list(scoring) + [1 if use_jump else 0, len(sites)] + list(sites) + [0] * (16 - len(sites)),
-                      dtype=torch.int32, device=dev)
+    # (two broadcasts: the fixed block with the number of sites, then exactly that many sites -- no fixed-size slot)
+    sc = torch.tensor(list(scoring) + [1 if use_jump else 0, len(sites)], dtype=torch.int32, device=dev)
+    st = torch.tensor(list(sites), dtype=torch.int32, device=dev)
     if use_dist:
         if rank != 0:
             sc.zero_()
         dist.broadcast(sc, src=0)
+        ns = int(sc[6].item())
+        if ns:
+            if rank != 0:
+                st = torch.zeros(ns, dtype=torch.int32, device=dev)
+            dist.broadcast(st, src=0)
         torch.cuda.synchronize()
         sys.stdout.flush()
         os.dup2(saved_stdout, 1)
         os.close(saved_stdout)
     scl = sc.cpu().tolist()
     m, u, o, e, j, uj, ns = scl[:7]
+    site_list = st.cpu().tolist()[:ns]
     S = max(1, args.streams)
     LAG = S                                          # the CIGAR payload of step k is sent when its stream comes round again
     NB = S + 2                                       # buffer sets, used in turn
     als = [A.Aligner(local_rank) for _ in range(S)]  # one handle (workspace, work queue) per stream
     for x in als:
-        x.set_scoring(m, u, o, e, j, bool(uj), scl[7:7 + ns])
+        x.set_scoring(m, u, o, e, j, bool(uj), site_list)
     al = als[0]
     streams = [torch.cuda.Stream(device=dev) for _ in range(S)] if S > 1 else [torch.cuda.current_stream()]
 

@@ -81,7 +81,10 @@ int at_set_scoring(at_handle *h, int m, int u, int o, int e, int j,
  *   out_state[n]      AT_ST_* start state
  *   out_ops, ops_off[n], out_nops[n]
  *                     ops of pair k are written to out_ops[ops_off[k] ..] (at
- *                     most len1+len2 of them), count in out_nops[k]
+ *                     most len1+len2 of them), count in out_nops[k].  Exactly
+ *                     out_nops[k] bytes of a slot are written; bytes between and
+ *                     behind the slots are never touched, and the slots may come
+ *                     in any order (they must not overlap).
  * Any out_* may be NULL if not wanted (out_ops/ops_off/out_nops together).
  */
 int at_align_batch(at_handle *h, int mode, int64_t npairs,
@@ -96,6 +99,10 @@ int at_align_batch(at_handle *h, int mode, int64_t npairs,
  * Same, with every buffer already resident in DEVICE memory (HBM) and the
  * sequences already packed (at_pack_batch): the entry the batch driver and
  * bench.py use.  Asynchronous on `stream` (a hipStream_t, NULL = default).
+ * A handle owns one work counter, one workspace and one flag word: use it with
+ * ONE stream at a time (calls queued on the same stream may follow each other
+ * without waiting; a call on another stream needs the earlier ones finished --
+ * or its own handle, which is how bench.py keeps three launches in flight).
  *   d_seq      packed words; bits = 2 (A,C,G,T -> 0..3, 16 bases per int32,
  *              base k of a sequence in bits [2k%32, 2k%32+1] of word k/16) or
  *              bits = 8 (4 bytes per int32, little endian)

@@ -31,11 +31,12 @@ rank = dist.get_rank()
 rng = random.Random(5)
 pairs = [("".join(rng.choice("ACGT") for _ in range(rng.randint(5, 40))), "".join(rng.choice("ACGT") for _ in range(rng.randint(41, 80)))) for _ in range(%(n)d)]
 # only rank 0 knows the real scoring; the others start from defaults and must receive it
-opt = A.opt_t(m=2, u=-2, o=-5, e=-2, j=-7, s=True, sites=[10, 20, 30]) if rank == 0 else A.opt_t()
+SITES = [10, 20, 30] + list(range(100, 400))   # 303 sites: the list has no fixed-size slot in the broadcast
+opt = A.opt_t(m=2, u=-2, o=-5, e=-2, j=-7, s=True, sites=SITES) if rank == 0 else A.opt_t()
 out = {}
 for mode in ("local", "fit", "edit"):
     res, got = align_sharded(mode, pairs, opt, compute=compute)
-    assert (got.m, got.u, got.o, got.e, got.j, got.s, got.sites) == (2, -2, -5, -2, -7, True, [10, 20, 30])
+    assert (got.m, got.u, got.o, got.e, got.j, got.s, got.sites) == (2, -2, -5, -2, -7, True, SITES)
     out[mode] = dict(score=res["score"].tolist(), nops=res["nops"].tolist(), ops=[o.hex() for o in res.get("ops", [])])
 print("RESULT" + json.dumps(dict(rank=rank, out=out, ranges=[shard_range(%(n)d, r, 2) for r in range(2)])))
 dist.destroy_process_group()
@@ -64,7 +65,7 @@ def test_two_rank_gloo_shard_broadcast_gather(tmp_path):
     rng = random.Random(5)
     pairs = [("".join(rng.choice("ACGT") for _ in range(rng.randint(5, 40))), "".join(rng.choice("ACGT") for _ in range(rng.randint(41, 80)))) for _ in range(n)]
     for mode in ("local", "fit", "edit"):
-        ref = [O.align(O.MODE_NAMES[mode], a, b, 2, -2, -5, -2, -7, True, [10, 20, 30]) for a, b in pairs]
+        ref = [O.align(O.MODE_NAMES[mode], a, b, 2, -2, -5, -2, -7, True, [10, 20, 30] + list(range(100, 400))) for a, b in pairs]
         assert outs[0]["out"][mode]["score"] == [r["score"] for r in ref]
         if mode != "edit":
             assert outs[0]["out"][mode]["ops"] == [r["ops"].hex() for r in ref]

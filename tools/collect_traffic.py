@@ -61,6 +61,7 @@ def main():
     ap.add_argument("--round", type=int, default=2)
     ap.add_argument("--no-traceback", action="store_true")
     args = ap.parse_args()
+    args.out = os.path.abspath(args.out)   # rocprofv3 runs with cwd=/tmp
     os.makedirs(args.out, exist_ok=True)
     extra = ["--no-traceback"] if args.no_traceback else []
     for w in args.workloads:

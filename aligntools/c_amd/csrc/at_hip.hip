@@ -282,16 +282,20 @@ struct Layout16 {
 	long long words;
 };
 
-/* Group width: reads of up to 208 bases run as 4 groups of 16 lanes x K rows (8 alignments per wave, 85 % of the
- * lane-steps inside a 150 x 150 matrix instead of 59 %), reads of 209..416 bases as 2 groups of 32 lanes, everything
- * else as one group of 64 lanes. */
+/* Group width: reads of up to 152 bases run as 8 groups of 8 lanes x K rows (16 alignments per wave: 94 % of the
+ * lane-steps inside a 150 x 150 matrix, the per-step overhead spread over 19 rows), up to 208 bases as 4 groups of 16
+ * lanes (8 alignments per wave, 85 %; one group of 64 lanes: 59 %), 209..416 bases as 2 groups of 32 lanes, everything
+ * else as one group of 64 lanes.  AT_GROUP = 16 / 64 caps the choice (A/B runs); ragged frames use the 16-lane kernels. */
 static Layout16 layout16_for(bool tb, bool hasj, int l1, int l2, int ts, bool force16 = false)
 {
 	Layout16 L;
 	const long long g_forced = env_ll("AT_GROUP", 0);
 	L.g = 64;
 	L.k = rows_per_lane(l1);
-	if ((force16 || g_forced != 64) && ts == 4 && l1 <= 208) {
+	if (!force16 && (g_forced == 0 || g_forced == 8) && ts == 4 && l1 <= 152) {
+		L.g = 8;
+		L.k = l1 <= 40 ? 5 : l1 <= 56 ? 7 : l1 <= 80 ? 10 : l1 <= 104 ? 13 : l1 <= 128 ? 16 : 19;
+	} else if ((force16 || g_forced != 64) && ts == 4 && l1 <= 208) {
 		L.g = 16;
 		L.k = l1 <= 64 ? 4 : l1 <= 80 ? 5 : l1 <= 96 ? 6 : l1 <= 112 ? 7 : (l1 <= 160 ? 10 : 13);
 	} else if (g_forced != 64 && ts == 4 && l1 > 208 && l1 <= 416) {
@@ -301,7 +305,7 @@ static Layout16 layout16_for(bool tb, bool hasj, int l1, int l2, int ts, bool fo
 		L.k = l1 <= 224 ? 7 : l1 <= 256 ? 8 : l1 <= 320 ? 10 : 13;
 	}
 	const int ng = 64 / L.g;
-	const int blk = L.g == 16 ? 4 : 8;        /* BLK of at_sweep16 */
+	const int blk = L.g <= 16 ? 4 : 8;        /* BLK of at_sweep16 */
 	const int tbk = (l2 + L.g - 1 + blk - 1) / blk;
 	L.ptr_lanes = L.g == 64 ? std::max(1, std::min(64, (l1 + L.k - 1) / L.k)) : 64;
 	L.ptr_lanes = (L.ptr_lanes + 3) & ~3;     /* the HBM slot stores 16 bytes per lane: keep every group of rows aligned */
@@ -401,7 +405,7 @@ static int ensure_sitemask(at_handle *h, int max_l2, hipStream_t stream)
  * Work is handed out through an atomic counter, so the grid only has to cover the waves that
  * can be resident; over-estimating it is harmless. */
 struct Plan {
-	int store, off_ptr;
+	int store, off_ptr, off_extra;   /* off_extra: LDS word offset of the caller's extra block (walk states) */
 	long long grid, slot_words;
 	size_t dyn_lds;
 	uint32_t *ws;
@@ -431,10 +435,11 @@ static int choose_store(long long words_fixed, long long words_ptr, bool prefer_
 
 static int plan_launch(at_handle *h, const char *tag, int k, long long nwork, long long words_fixed, long long words_ptr,
                        Plan *pl, hipStream_t stream, const std::function<const void *(int)> &kernel_for_store,
-                       bool prefer_hbm_pointers = false)
+                       bool prefer_hbm_pointers = false, int slots_per_wave = 1, int extra_lds_words = 0)
 {
 	const int store = choose_store(words_fixed, words_ptr, prefer_hbm_pointers);
-	const long long lds_words = store == 0 ? words_fixed + words_ptr : (store == 1 ? words_fixed : 0);
+	const long long lds_base = store == 0 ? words_fixed + words_ptr : (store == 1 ? words_fixed : 0);
+	const long long lds_words = lds_base + extra_lds_words;
 	const long long slot_words = store == 0 ? 0 : (((store == 1 ? words_ptr : words_fixed + words_ptr) + 63) & ~63LL);
 	long long per_cu = 16;
 	if (lds_words > 0) per_cu = std::min<long long>(per_cu, (long long)(h->lds_per_cu - 512) / std::max<long long>(lds_words * 4, 256));
@@ -450,15 +455,17 @@ static int plan_launch(at_handle *h, const char *tag, int k, long long nwork, lo
 	 * waves cost 5-13 % more than the partial last round they avoid.) */
 	pl->store = store;
 	pl->off_ptr = store == 1 ? 0 : (int)words_fixed;
+	pl->off_extra = (int)((lds_base + 3) & ~3LL);   /* 16-byte aligned (the 4 words of slack are in extra_lds_words) */
 	pl->dyn_lds = (size_t)lds_words * 4;
 	pl->slot_words = slot_words;
 	pl->ws = nullptr;
 	if (slot_words > 0) {
 		const long long cap = env_ll("AT_WS_CAP_MB", 16384) << 20;
 		if (slot_words * 4 > cap) return fail(h, AT_ERR_NOMEM, "one pair needs %lld workspace bytes (cap %lld)", slot_words * 4, cap);
-		grid = std::max(1LL, std::min(grid, cap / (slot_words * 4)));
+		/* (the packed kernels with deferred tracebacks alternate between two slots per wave, at_sweep16.hip.h PIPE) */
+		grid = std::max(1LL, std::min(grid, cap / (slot_words * 4 * slots_per_wave)));
 		void *p = h->d_ws; size_t have = h->ws_bytes;
-		int rc = grow(h, &p, &have, (size_t)(grid * slot_words * 4));
+		int rc = grow(h, &p, &have, (size_t)(grid * slot_words * 4 * slots_per_wave));
 		h->d_ws = (uint32_t *)p; h->ws_bytes = have;
 		if (rc) return rc;
 		pl->ws = h->d_ws;
@@ -678,9 +685,11 @@ static int align_device(at_handle *h, int mode, int64_t npairs,
 		         rag ? " ragged frames" : "");
 		auto pick = [&](int st) { return rag ? at_pick16_rag(P.k, st, tb, bits) : at_pick16(kmode, P.g, P.k, ts, st, tb, bits); };
 		int rc = plan_launch(h, tag16, P.k, (npairs + per_wave - 1) / per_wave, P.off_ptr, P.words - P.off_ptr, &pl, stream,
-		                     [&](int st) { return (const void *)pick(st); }, P.g < 64);
+		                     [&](int st) { return (const void *)pick(st); }, P.g < 64,
+		                     tb && (kmode == at::K_FIT || kmode == at::K_FITJ) ? 2 : 1 /* deferred tracebacks: two slots per wave */, tb ? 128 + 4 : 0);
 		if (rc) return rc;
 		b.off_ptr = pl.off_ptr; b.ws = pl.ws; b.ws_slot_words = pl.slot_words; b.queue = h->d_queue;
+		b.off_wk = pl.off_extra;           /* 16-byte aligned: the walk states are read and written 4 words at a time */
 		at_sweep16_fn fn16 = pick(pl.store);
 		if (!fn16 || (P.g != 64 && pl.store == 2)) return fail(h, AT_ERR_RANGE, "no packed kernel for this shape (rows/lane=%d, store=%d)", P.k, pl.store);
 		if (pl.dyn_lds > 48 * 1024)

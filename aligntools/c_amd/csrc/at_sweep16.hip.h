@@ -56,6 +56,7 @@ struct Sweep16Args {
 	uint32_t *ws;
 	long long ws_slot_words;
 	int off_refb, off_bound, off_ptr, off_sm, nsm;   /* off_sm/nsm: site mask words staged behind the boundary row */
+	int off_wk;                    /* LDS word offset of the walk states (64 words; kernels with tracebacks) */
 	int ptr_lanes;
 	unsigned long long *queue;     /* work counter, zeroed before every launch */
 	/* RAG kernels (local, ragged batch): l1 / l2 are the FRAME every work item is swept in, len1 / len2 the pairs' own
@@ -133,7 +134,7 @@ AT_DEV int sat16(int v) { return v < -32768 ? -32768 : (v > 32767 ? 32767 : v); 
 
 /* second __launch_bounds__ argument = waves per SIMD the register allocator must leave room for */
 #ifndef AT_WAVES16
-#define AT_WAVES16(G, K) (((G) == 16 || (G) == 32) && (K) >= 10 ? 3 : 1)
+#define AT_WAVES16(G, K) ((G) == 8 ? ((K) >= 16 ? 2 : (K) >= 10 ? 3 : 1) : ((G) == 16 || (G) == 32) && (K) >= 10 ? 3 : 1)
 #endif
 
 /* shift up by one lane inside a group of G lanes; lane 0 of each group keeps `old` */
@@ -145,6 +146,11 @@ AT_DEV uint32_t grp_up1(uint32_t old, uint32_t src)
 		/* two DPP rows per group: shift across the whole wave, then give lane 32 (lane 0 of the second group) its own `old` */
 		const uint32_t v = (uint32_t)__builtin_amdgcn_update_dpp((int)old, (int)src, 0x138 /* wave_shr:1 */, 0xf, 0xf, false);
 		return threadIdx.x == 32 ? old : v;
+	}
+	else if constexpr (G == 8) {
+		/* two groups per DPP row of 16: lane 8 of a row (lane 0 of the second group) keeps its own `old` */
+		const uint32_t v = (uint32_t)__builtin_amdgcn_update_dpp((int)old, (int)src, 0x111 /* row_shr:1 */, 0xf, 0xf, false);
+		return (threadIdx.x & 15) == 8 ? old : v;
 	}
 	else return (uint32_t)__builtin_amdgcn_update_dpp((int)old, (int)src, 0x111 /* row_shr:1 */, 0xf, 0xf, false);
 }
@@ -172,6 +178,9 @@ __global__ __launch_bounds__(64, AT_WAVES16(G, K)) void at_sweep16(const Sweep16
 	constexpr bool ISFIT = MODE == K_FIT || MODE == K_FITJ;
 	static_assert(TS == 4 || (TS == 2 && K <= 4), "TS = 2: the local row tag must fit 2 bits");
 	constexpr int TMASK = (1 << TS) - 1;      /* tag bits of a score */
+	/* local arg-max: the key of a cell carries its row-in-lane in the tag bits, so one running maximum covers TMASK + 1
+	 * rows; lanes with more rows (8-lane groups: up to 19) keep one chain per TMASK + 1 rows */
+	constexpr int CS = TMASK + 1, NCH = (K + CS - 1) / CS;
 	/* priority tags in the low bits of every score make v_pk_max pick the reference's first-wins candidate.  They decide
 	 * pointers, never values: the kernels without a pointer matrix (TB = false) run without them, three instructions
 	 * per row-step less, and tag the three end-cell candidates of global only to report the start state. */
@@ -179,22 +188,32 @@ __global__ __launch_bounds__(64, AT_WAVES16(G, K)) void at_sweep16(const Sweep16
 	constexpr int TGL = TB ? OTGL : 0, TGM = TB ? OTGM : 0, TGU = TB ? OTGU : 0;
 	constexpr int PB = HASJ ? 8 : 4;          /* pointer bits per cell and alignment */
 	constexpr int SPW = 16 / PB;              /* steps per pointer word (each half holds its own alignment) */
-	static_assert(G == 64 || G == 32 || G == 16, "group width");
+	static_assert(G == 64 || G == 32 || G == 16 || G == 8, "group width");
 	constexpr int NG = 64 / G;                /* groups per wavefront, 2 alignments each */
 	/* steps per unrolled block.  The 16-lane kernels carry 7..13 rows per lane, so 4 steps (one pointer word) already
 	 * unroll to ~6 KB of code and only one (masked) body is emitted: every launch starts with a cold instruction
 	 * cache, and at ~1 ms per launch the first pass through tens of KB of straight-line code is measurable. */
-	constexpr int BLK = G == 16 ? 4 : 8;
-	constexpr bool ONEBODY = G == 16;
+	constexpr int BLK = G <= 16 ? 4 : 8;
+	constexpr bool ONEBODY = G <= 16;
 	constexpr int RPB = BLK / SPW;            /* pointer word rows per block */
 	constexpr int RS = G * K;                 /* rows per strip (G < 64: the only strip) */
+	/* Deferred tracebacks (pointer matrix in the global slot): the pointer walks of work item n run INSIDE the sweep of
+	 * work item n+1 of the same wave, one op per sweep step, each op's pointer word loaded one step ahead -- the walks'
+	 * dependent HBM loads (hundreds of them for fit / global) then cost the wave no idle time of its own.  The sweep of
+	 * item n+1 must not overwrite the pointers item n's walks still read: a wave owns TWO slots and alternates.
+	 * Used for the fit modes, whose walks cross the whole read (C4: the waves of a SIMD otherwise sit in their walks at
+	 * the same time for a fifth of the run; 1 617 -> 1 785 GCUPS).  Local and global batches already run at the VALU
+	 * issue bound with the walks where they are, and the per-step bookkeeping of deferring them costs 7-8 % there. */
+	constexpr bool PIPE = TB && !PTRLDS && (MODE == K_FIT || MODE == K_FITJ);
 	constexpr int PADW = kPad / 4;            /* s2 bytes: 4 per word */
 	const int lane = threadIdx.x;
 	const int grp = lane / G, lg = lane % G;
 	Slot<SMALL> mem;
-	mem.g = SMALL ? nullptr : a.ws + (long long)blockIdx.x * a.ws_slot_words;
-	PtrStore<PTRLDS> pm;
-	pm.g = PTRLDS ? nullptr : a.ws + (long long)blockIdx.x * a.ws_slot_words;
+	uint32_t *const slot0 = a.ws + (long long)blockIdx.x * (PIPE ? 2 : 1) * a.ws_slot_words;
+	mem.g = SMALL ? nullptr : slot0;
+	PtrStore<PTRLDS> pm, pr;                  /* pm: the slot this sweep writes; pr: the slot the pending walks read */
+	pm.g = PTRLDS ? nullptr : slot0;
+	pr.g = pm.g;
 	const int l1 = a.l1, l2 = a.l2, NL = a.ptr_lanes;
 	const int o16 = a.o16, e16 = a.e16;
 	uint32_t o2 = pk2(a.o16), e2 = pk2(a.e16);
@@ -223,10 +242,105 @@ __global__ __launch_bounds__(64, AT_WAVES16(G, K)) void at_sweep16(const Sweep16
 	const int refoff = grp * 2 * a.off_refb;  /* my group's two s2 byte arrays */
 
 	if (a.only_if && __builtin_amdgcn_readfirstlane(*a.only_if) != a.only_val) return;
+
+	/* ---- pointer walks (trace_back_*: alignment.h:372-412, 558-592, 766-800), one per lane so that the walks of a work
+	 *      item overlap: lane q < 2*NG walks alignment q = 2*group + half.  A walk is a small state machine advanced one
+	 *      op per walk_tick(); the pointer word of the cell it stands on is loaded one tick ahead (wkpend).  Its state
+	 *      lives in LDS (8 words per walker lane at a.off_wk), not in registers: with deferred tracebacks it is alive
+	 *      across the whole sweep of the next work item, whose unrolled step body needs every VGPR it can get.
+	 *      words: 0 ci, 1 cj, 2 {st (3 LOW, 2 MID, 1 UPP, 0 JUMP/HOME; 0xff: no walk pending), ok << 8, shift << 16},
+	 *             3 ops written so far, 4-5 the ops slot, 6-7 the pair index ---- */
+	uint32_t wkpend = 0;                   /* pointer word of the cell the walk stands on */
+	bool walking = false;                  /* wave-uniform: some lane has a walk pending */
+	const int wko = a.off_wk + (lane & 15) * 8;   /* (at most 16 walker lanes: 8 groups of 8 lanes) */
+	const bool walker = lane < 2 * NG;
+	const int wglane = (lane >> 1) * G;    /* lane 0 of the group whose alignment this lane walks */
+	const int wh = lane & 1;
+	/* one more pointer cell to read, or done: padding ops, count (called at the start and after every op) */
+	auto walk_next = [&](int &ci, int &cj, int &st, int &cnt, bool &ok, int &sh, uint8_t *ops, long long p) {
+		bool more = ok && ci > 0 && (ISFIT || cj > 0) && !(MODE == K_LOCAL && st == 0);   /* HOME :788-791 */
+		if (more && (cj <= 0 || cnt >= l1 + l2)) { ok = false; more = false; }
+		if (more) {
+			const int ss = G == 64 ? (ci - 1) / RS : 0, li = G == 64 ? (ci - 1) % RS : ci - 1;
+			const int ln = li / K, r = li % K;
+			const int t = (cj - 1) + ln;
+			sh = 16 * wh + PB * (SPW - 1 - (t % SPW));
+			wkpend = pr.ld(a.off_ptr + ss * wps * NL + pidx<PTRLDS, K>(t / SPW, r, wglane + ln, NL));
+		} else {
+			if constexpr (MODE == K_GLOBAL) {                 /* padding loops :398-407 */
+				if (ok) {
+					while (cj > 0) { ops[cnt++] = 2; --cj; }
+					while (ci > 0) { ops[cnt++] = 1; --ci; }
+				}
+			}
+			if (a.nops) a.nops[p] = ok ? cnt : -1;
+			if (!ok) a.score[p] = INT32_MIN;
+			st = -1;
+		}
+	};
+	auto walk_op = [&](int &ci, int &cj, int &st, int &cnt, bool &ok, int &sh, uint8_t *ops, long long p) {
+		/* nibble {bit 3: U winner, bit 2: L winner, pM[1:0]} (+ bit 4: J came from M).  Bit 3 is bit 3 of the
+		 * winner's tag for TS = 4 (M's 10 has it) and bit 0 for TS = 2 (U's 1 has it). */
+		const uint32_t nb = (wkpend >> sh) & ((1u << PB) - 1u);
+		const bool l_ext = (nb & 4u) != 0;
+		const bool u_open = TS == 4 ? (nb & 8u) != 0 : (nb & 8u) == 0;
+		const bool j_open = (nb & 16u) != 0;
+		int op = 0;
+		if (st == 3) { st = l_ext ? 3 : 2; op = 1; --ci; }
+		else if (st == 2) { st = (int)(nb & 3u); op = 0; --ci; --cj; }
+		else if (st == 1) { st = u_open ? 2 : 1; op = 2; --cj; }
+		else if (HASJ) { st = j_open ? 2 : 0; op = 3; --cj; }       /* jump state :579-583 */
+		else ok = false;
+		if (ok) ops[cnt++] = (uint8_t)op;
+		walk_next(ci, cj, st, cnt, ok, sh, ops, p);
+	};
+	auto walk_store = [&](int ci, int cj, int st, int cnt, bool ok, int sh) {
+		*reinterpret_cast<uint4 *>(&at_lds[wko]) = make_uint4((uint32_t)ci, (uint32_t)cj, ((uint32_t)st & 0xffu) | (ok ? 0x100u : 0u) | ((uint32_t)sh << 16), (uint32_t)cnt);
+	};
+	auto walk_tick = [&]() {               /* deferred mode: one op of every pending walk */
+		bool act = false;
+		if (walker) {
+			const uint4 s0 = *reinterpret_cast<const uint4 *>(&at_lds[wko]);
+			int st = (int)(int8_t)(s0.z & 0xffu);
+			if (st >= 0) {
+				const uint4 s1 = *reinterpret_cast<const uint4 *>(&at_lds[wko + 4]);
+				uint8_t *ops = reinterpret_cast<uint8_t *>(((unsigned long long)s1.y << 32) | s1.x);
+				const long long p = (long long)(((unsigned long long)s1.w << 32) | s1.z);
+				int ci = (int)s0.x, cj = (int)s0.y, cnt = (int)s0.w, sh = (int)(s0.z >> 16);
+				bool ok = (s0.z & 0x100u) != 0;
+				walk_op(ci, cj, st, cnt, ok, sh, ops, p);
+				walk_store(ci, cj, st, cnt, ok, sh);
+				act = st >= 0;
+			}
+		}
+		walking = __any(act);
+	};
+	/* start the walk of alignment `lane` of a work item from its end cell and leave it pending */
+	auto walk_start = [&](bool mine, long long p, int ci, int cj, int st, bool ok) {
+		int cnt = 0, sh = 0;
+		uint8_t *ops = nullptr;
+		if (mine) {
+			ops = a.ops + a.ops_off[p];
+			walk_next(ci, cj, st, cnt, ok, sh, ops, p);
+		} else st = -1;
+		if (walker) {
+			if (mine)
+				*reinterpret_cast<uint4 *>(&at_lds[wko + 4]) = make_uint4((uint32_t)(unsigned long long)ops, (uint32_t)((unsigned long long)ops >> 32),
+				                                                          (uint32_t)(unsigned long long)p, (uint32_t)((unsigned long long)p >> 32));
+			walk_store(ci, cj, st, cnt, ok, sh);
+		}
+		walking = __any(st >= 0);
+	};
+
+	int par = 0;                           /* PIPE: which of the wave's two slots the next sweep writes */
 	long long wnext = blockIdx.x;
 	while (wnext < nwork) {
 		const long long wk = wnext;
 		wnext = next_work(a.queue, lane);   /* consumed at the end of this work item: latency hidden */
+		if constexpr (PIPE) {
+			pm.g = slot0 + par * a.ws_slot_words;
+			if constexpr (!SMALL) mem.g = pm.g;
+		}
 		const long long last = a.npairs - 1;
 		long long pA = (wk * NG + grp) * 2 < a.npairs ? (wk * NG + grp) * 2 : last;
 		long long pB = (wk * NG + grp) * 2 + 1 < a.npairs ? (wk * NG + grp) * 2 + 1 : last;
@@ -341,7 +455,9 @@ __global__ __launch_bounds__(64, AT_WAVES16(G, K)) void at_sweep16(const Sweep16
 				L = sat16(L);
 				Ad = pk2(imax3(L | TGL, M | TGM, U | TGU));
 			}
-			uint32_t best = 0x80008000u, bt = 0;   /* local: per-lane (key, step) of this strip */
+			uint32_t best[NCH], bt[NCH];           /* local: per-lane (key, step) of this strip, per chain of rows */
+#pragma unroll
+			for (int c = 0; c < NCH; ++c) { best[c] = 0x80008000u; bt[c] = 0; }
 			auto load_bound = [&](int t0, uint32_t &bx, uint32_t &bl) {
 				const int jn = imin(t0 + 1 + (lane & 7), l2);
 				const uint2 v = mem.ld2(a.off_bound + 2 * jn);
@@ -413,7 +529,7 @@ __global__ __launch_bounds__(64, AT_WAVES16(G, K)) void at_sweep16(const Sweep16
 						}
 						/* step k's byte of each window against each of my query bases */
 						const uint32_t selw = __builtin_amdgcn_perm(wB[hw], wA[hw], SELK);   /* [b, b, a, a] */
-						uint32_t diag = Ad, lraw = Bup, up = 0, cmax = 0;
+						uint32_t diag = Ad, lraw = Bup, up = 0, cmax[NCH];
 #pragma unroll
 						for (int r = 0; r < K; ++r) {
 							/* x = s2 byte ^ query byte (0 = match): selector {xB+4, xB, xA+4, xA} -> the two 16-bit scores */
@@ -467,9 +583,9 @@ __global__ __launch_bounds__(64, AT_WAVES16(G, K)) void at_sweep16(const Sweep16
 								}
 							}
 							if constexpr (MODE == K_LOCAL) {
-								uint32_t rt = (uint32_t)(K - 1 - r) * 0x00010001u;
+								uint32_t rt = (uint32_t)(TMASK - r % CS) * 0x00010001u;
 								const uint32_t key = (Mraw & keymask[r]) | rt;
-								cmax = r == 0 ? key : pmax(cmax, key);
+								cmax[r / CS] = r % CS == 0 ? key : pmax(cmax[r / CS], key);
 							}
 							diag = Xl[k & 1][r];
 							Xl[(k & 1) ^ 1][r] = Xo;
@@ -483,13 +599,17 @@ __global__ __launch_bounds__(64, AT_WAVES16(G, K)) void at_sweep16(const Sweep16
 								/* columns behind an alignment's own l2 are swept (they feed nothing inside it) but must
 								 * not win its arg-max */
 								const uint32_t cm = (((uint32_t)((jm1 - l2A) >> 31)) & 0xffffu) | (((uint32_t)((jm1 - l2B) >> 31)) << 16);
-								cmax = vbfi(cm, cmax, neg2);
+#pragma unroll
+								for (int c = 0; c < NCH; ++c) cmax[c] = vbfi(cm, cmax[c], neg2);
 							}
-							uint32_t dlt = psub(best, cmax);
-							asm("" : "+v"(dlt));                        /* keep hipcc from turning this into 2 cmp + 2 cndmask + perm */
-							const uint32_t g = pneg(dlt);               /* 0xffff where cmax > best */
-							bt = vbfi(g, tpk, bt);
-							best = pmax(best, cmax);
+#pragma unroll
+							for (int c = 0; c < NCH; ++c) {
+								uint32_t dlt = psub(best[c], cmax[c]);
+								asm("" : "+v"(dlt));                    /* keep hipcc from turning this into 2 cmp + 2 cndmask + perm */
+								const uint32_t g = pneg(dlt);           /* 0xffff where cmax > best */
+								bt[c] = vbfi(g, tpk, bt[c]);
+								best[c] = pmax(best[c], cmax[c]);
+							}
 						}
 						A_prev = up; B_prev = lraw;
 						if (wb && lane == 63) mem.st2(a.off_bound + 2 * (jm1 + 1), up, lraw);
@@ -502,6 +622,9 @@ __global__ __launch_bounds__(64, AT_WAVES16(G, K)) void at_sweep16(const Sweep16
 						for (int r = 0; r < K; ++r) acc[r] = PB == 8 ? pshl8(acc[r]) : pshl4(acc[r]);
 					}
 					Ad = Aup;
+					if constexpr (PIPE) {
+						if (walking) walk_tick();   /* the previous work item's walks: one op per sweep step */
+					}
 					if constexpr (TB) {
 						if ((k + 1) % SPW == 0 && lane < NL) {
 							if constexpr (PTRLDS) {
@@ -544,14 +667,17 @@ __global__ __launch_bounds__(64, AT_WAVES16(G, K)) void at_sweep16(const Sweep16
 			if constexpr (MODE == K_LOCAL) {
 				/* fold this strip's per-lane winner into the running one (earlier strips = smaller i win ties) */
 #pragma unroll
-				for (int h = 0; h < 2; ++h) {
-					const int key = half(best, h);
-					const int sc = key & ~TMASK;
-					const int row = i0 + (K - 1 - (key & TMASK)) + 1;
-					if (key != kNeg16 && row <= (h == 0 ? l1A : l1B) && sc > gbs[h]) {
-						gbs[h] = sc;
-						gbi[h] = row;
-						gbj[h] = (int)((bt >> (16 * h)) & 0xffffu) - lg + 1;
+				for (int c = 0; c < NCH; ++c) {        /* chains in row order: the earlier chain keeps a tie */
+#pragma unroll
+					for (int h = 0; h < 2; ++h) {
+						const int key = half(best[c], h);
+						const int sc = key & ~TMASK;
+						const int row = i0 + c * CS + (TMASK - (key & TMASK)) + 1;
+						if (key != kNeg16 && row <= (h == 0 ? l1A : l1B) && sc > gbs[h]) {
+							gbs[h] = sc;
+							gbi[h] = row;
+							gbj[h] = (int)((bt[c] >> (16 * h)) & 0xffffu) - lg + 1;
+						}
 					}
 				}
 			}
@@ -597,14 +723,26 @@ __global__ __launch_bounds__(64, AT_WAVES16(G, K)) void at_sweep16(const Sweep16
 			}
 			if (lane == gh) { my_sc = sc16; my_ci = ci; my_cj = cj; my_st = st; my_ok = ok; }
 		}
-		/* ================= tracebacks: the 2*NG pointer walks run side by side, one per lane, so their
+		/* ================= results; tracebacks: the 2*NG pointer walks run side by side, one per lane, so their
 		 *                   dependent pointer loads overlap instead of queueing behind each other ================= */
 		{
 			const int g = lane >> 1, h = lane & 1;
 			const long long pin = (wk * NG + g) * 2 + h;          /* = wk * 2 * NG + lane */
 			const bool mine = lane < 2 * NG && pin < a.npairs;
 			const long long p = RAG ? pout : pin;                  /* RAG: the host's order array says which pair this is */
-			if (mine) {
+			if constexpr (PIPE) {
+				/* deferred: the results go out now, the walk is left pending for the next sweep's steps */
+				if (mine) {
+					a.score[p] = my_ok ? (my_sc >> TS) : INT32_MIN;
+					if (a.end_i) a.end_i[p] = my_ci;
+					if (a.end_j) a.end_j[p] = my_cj;
+					if (a.state) a.state[p] = my_st == 3 ? 1 : my_st == 2 ? 2 : 3;
+				}
+				while (walking) walk_tick();                       /* (walks that outlasted this sweep) */
+				pr.g = pm.g;                                       /* the new walks read the slot just written ... */
+				par ^= 1;                                          /* ... while the next sweep fills the other one */
+				walk_start(mine, p, my_ci, my_cj, my_st, my_ok);
+			} else if (mine) {
 				int ci = my_ci, cj = my_cj, st = my_st, cnt = 0;
 				bool ok = my_ok;
 				if constexpr (TB) {
@@ -649,6 +787,7 @@ __global__ __launch_bounds__(64, AT_WAVES16(G, K)) void at_sweep16(const Sweep16
 		}
 		mem.sync();
 	}
+	if constexpr (PIPE) { while (walking) walk_tick(); }
 }
 
 } /* namespace at */

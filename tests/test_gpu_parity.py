@@ -422,7 +422,7 @@ def test_device_entry_refuses_broken_uniform_promise(al):
     assert "packed16" in al.last_config
     score, nops = d_res[0].cpu().numpy(), d_nops.cpu().numpy()
     refused = np.flatnonzero(score == np.iinfo(np.int32).min)
-    assert 37 in refused and len(refused) <= 8 and (nops[refused] == -1).all()
+    assert 37 in refused and len(refused) <= 16 and (nops[refused] == -1).all()   # a work item: up to 16 pairs
     for k in range(n):
         if k not in refused:
             assert int(score[k]) == O.align(O.LOCAL, pairs[k][0], pairs[k][1], 2, -2, -5, -2)["score"]
@@ -921,3 +921,109 @@ def test_packed_32_lane_groups(al, mode):
             r = O.align(O.MODE_NAMES[m], x, y, *sc, uj, [50, 150, 250])
             assert (int(res["score"][k]), int(res["end_i"][k]), int(res["end_j"][k]), int(res["state"][k]), res["ops"][k]) == \
                    (r["score"], r["end_i"], r["end_j"], r["state"], r["ops"]), (mode, l1, l2, k)
+
+
+@pytest.mark.parametrize("mode", ["local", "global", "fit", "fitj"])
+def test_packed_8_lane_groups(al, mode):
+    """Reads of up to 152 bases run as eight groups of 8 lanes (16 alignments per wavefront), 5 / 7 / 10 / 13 / 16 / 19 rows per
+    lane: every class edge, both alphabets, related and unrelated pairs, batch sizes that leave the last work item partly
+    empty, against the oracle.  19 rows per lane exercise the second chain of the local arg-max (rows 16..18 of a lane)."""
+    rng = random.Random(808)
+    uj = mode == "fitj"
+    m = "fit" if uj else mode
+    for l1, l2, alpha, n in ((1, 9, "ACGT", 3), (36, 36, "ACGT", 40), (40, 120, "ACGT", 17), (41, 41, "ACGTN", 33), (56, 70, "ACGT", 16), (57, 57, "ACGT", 31),
+                             (80, 80, "ACGT", 48), (81, 150, "ACGTN", 19), (104, 104, "ACGT", 23), (105, 130, "ACGT", 32), (128, 128, "ACGT", 35),
+                             (129, 500, "ACGT", 21), (150, 150, "ACGT", 50), (150, 500, "ACGT", 37), (152, 152, "ACGTN", 18), (151, 153, "ACGT", 5)):
+        pairs = []
+        for k in range(n):
+            a = "".join(rng.choice(alpha) for _ in range(l1))
+            if k % 2:
+                t = list(a)
+                for _ in range(l1 // 18):
+                    q = rng.randrange(len(t))
+                    r = rng.random()
+                    if r < 0.5:
+                        t[q] = rng.choice(alpha)
+                    elif r < 0.75 and len(t) > 1:
+                        del t[q]
+                    else:
+                        t.insert(q, rng.choice(alpha))
+                b = ("".join(rng.choice(alpha) for _ in range(rng.randint(0, 25))) + "".join(t) + "".join(rng.choice(alpha) for _ in range(l2)))[:l2]
+            else:
+                b = "".join(rng.choice(alpha) for _ in range(l2))
+            pairs.append((a, b))
+        sc = (2, -2, -5, -2, -9) if mode != "global" else (1, -2, -4, -1, -9)
+        sites = [5, 50, 150, 250]
+        al.set_scoring(*sc, uj, sites)
+        for tb in (True, False):
+            res = al.align_batch(m, pairs, traceback=tb, render=False)
+            assert "8x8-lane groups" in al.last_config, (l1, l2, al.last_config)
+            for k, (x, y) in enumerate(pairs):
+                r = O.align(O.MODE_NAMES[m], x, y, *sc, uj, sites)
+                assert (int(res["score"][k]), int(res["end_i"][k]), int(res["end_j"][k]), int(res["state"][k])) == \
+                       (r["score"], r["end_i"], r["end_j"], r["state"]), (mode, l1, l2, k, tb)
+                if tb:
+                    assert res["ops"][k] == r["ops"], (mode, l1, l2, k)
+
+
+def test_short_read_against_long_target_falls_back_to_int32(al):
+    """A read of up to 208 bases against a second sequence too long for the packed kernels' LDS window (more than ~4 000
+    bases) has no packed instantiation: single pair, uniform batch and ragged batch all run on the int32 kernel and match
+    the oracle (round-1 advisor finding: they used to fail with AT_ERR_RANGE)."""
+    rng = random.Random(5150)
+    al.set_scoring(2, -2, -5, -2, -10, False, [])
+    for l2 in (5000, 20000):
+        for n, ragged in ((1, False), (9, False), (70, True)):
+            pairs = []
+            for k in range(n):
+                a = "".join(rng.choice("ACGT") for _ in range(150 - (k % 7 if ragged else 0)))
+                t = "".join(rng.choice("ACGT") for _ in range(l2 - (k * 13 if ragged else 0)))
+                q = rng.randrange(len(t) - 200)
+                t = t[:q] + a[10:140] + t[q + 130:]
+                pairs.append((a, t))
+            for mode in ("local", "fit"):
+                res = al.align_batch(mode, pairs, render=False)
+                for k in range(0, n, max(1, n // 6)):
+                    r = O.align(O.MODE_NAMES[mode], pairs[k][0], pairs[k][1], 2, -2, -5, -2, -10, False, [])
+                    assert (int(res["score"][k]), int(res["end_i"][k]), int(res["end_j"][k]), res["ops"][k]) == \
+                           (r["score"], r["end_i"], r["end_j"], r["ops"]), (mode, l2, n, k, al.last_config)
+
+
+def test_host_entry_writes_only_its_slots(al):
+    """at_align_batch writes exactly nops[k] bytes of pair k's slot and nothing between or behind the slots, whatever order
+    the slots are in (round-1 advisor finding: the whole span used to be copied back); at_align_batch_strings likewise
+    (nops[k] characters and the terminating 0)."""
+    import aligntools.c_amd as A
+    rng = random.Random(99)
+    pairs = [(A._b("".join(rng.choice("ACGT") for _ in range(60))), A._b("".join(rng.choice("ACGT") for _ in range(80)))) for _ in range(40)]
+    al.set_scoring(2, -2, -5, -2, -10, False, [])
+    ref = al.align_batch("local", pairs, render=True)
+    n = len(pairs)
+    blob, off1, len1, off2, len2 = A._flatten(pairs)
+    slot = 60 + 80 + 1
+    ops_off = np.array([(n - 1 - k) * (slot + 37) + 11 for k in range(n)], dtype=np.int64)   # reversed, with gaps
+    total = int(ops_off.max()) + slot + 100
+    for strings in (False, True):
+        score, ei, ej, st, nops = (np.zeros(n, dtype=np.int32) for _ in range(5))
+        b1 = np.full(total, 0xEE, dtype=np.uint8)
+        b2 = np.full(total, 0xEE, dtype=np.uint8)
+        if strings:
+            al._check(al._lib.at_align_batch_strings(al._h, A.MODES["local"], n, A._ptr(blob), A._ptr(off1), A._ptr(len1), A._ptr(off2), A._ptr(len2),
+                                                     A._ptr(score), A._ptr(ei), A._ptr(ej), A._ptr(st), A._ptr(b1), A._ptr(b2), A._ptr(ops_off), A._ptr(nops)))
+        else:
+            al._check(al._lib.at_align_batch(al._h, A.MODES["local"], n, A._ptr(blob), A._ptr(off1), A._ptr(len1), A._ptr(off2), A._ptr(len2), 1,
+                                             A._ptr(score), A._ptr(ei), A._ptr(ej), A._ptr(st), A._ptr(b1), A._ptr(ops_off), A._ptr(nops)))
+        assert (score == ref["score"]).all() and (nops == ref["nops"]).all()
+        written = np.zeros(total, dtype=bool)
+        for k in range(n):
+            o, c = int(ops_off[k]), int(nops[k])
+            if strings:
+                assert bytes(b1[o:o + c]).decode("latin1") == ref["r1"][k] and bytes(b2[o:o + c]).decode("latin1") == ref["r2"][k], k
+                assert b1[o + c] == 0 and b2[o + c] == 0
+                written[o:o + c + 1] = True
+            else:
+                assert bytes(b1[o:o + c]) == ref["ops"][k], k
+                written[o:o + c] = True
+        assert (b1[~written] == 0xEE).all(), "bytes outside the slots were written"
+        if strings:
+            assert (b2[~written] == 0xEE).all()

@@ -6,8 +6,9 @@
 //
 // Every kernel runs ITERS iterations of 64 independent instructions (8 accumulators x 8) in one wavefront per
 // workgroup; the grid is 256 CUs x 4 SIMDs x W workgroups, all resident at once, so every SIMD holds W waves.
-// Reported per instruction and W: cycles per wave64 instruction per SIMD = median over waves of
-// (delta s_memtime) x W / (ITERS x 64), the median clock, and the wall-clock view (HIP events) of the same launch.
+// Reported per instruction and W: `wave` = shader cycles between two consecutive instructions of ONE wave (median over
+// waves of delta s_memtime / (ITERS x 64)); `simd` = cycles per wave64 instruction per SIMD = the launch's HIP-event
+// time x the measured clock / (ITERS x 64 x W) -- the number a roofline needs; and the median clock in GHz.
 // The output of this program is the `cyc` table bench.py prices SQ_INSTS_VALU with (profiles/r02/valu_issue.json).
 #include <hip/hip_runtime.h>
 #include <algorithm>
@@ -148,11 +149,12 @@ int main(int argc, char **argv)
 	CK(hipGetDeviceProperties(&prop, 0));
 	const int cus = prop.multiProcessorCount;
 	printf("# device: %s, %d CUs, clockRate %d kHz; ITERS %d x 64 instructions per wave\n", prop.name, cus, prop.clockRate, ITERS);
-	printf("# cyc = shader cycles per wave64 instruction per SIMD (median over waves of delta s_memtime x W / instructions)\n");
-	printf("# GHz = median of delta s_memtime / delta s_memrealtime x 0.1; wall = HIP-event time of the launch -> cycles at that clock\n");
+	printf("# wave = shader cycles between consecutive instructions of one wave (median over waves of delta s_memtime / instructions)\n");
+	printf("# simd = cycles per wave64 instruction per SIMD: HIP-event time of the launch x measured clock / (instructions per wave x W)\n");
+	printf("# GHz  = median of delta s_memtime / delta s_memrealtime x 0.1\n");
 	printf("%-26s", "instruction");
 	const int Ws[] = {1, 2, 3, 4};
-	for (int w : Ws) printf("  W=%d cyc   GHz  wall", w);
+	for (int w : Ws) printf("  W=%d wave  simd   GHz", w);
 	printf("\n");
 	std::string js = "{\n \"device\": \"" + std::string(prop.name) + "\", \"cus\": " + std::to_string(cus) + ",\n \"unit\": \"shader cycles per wave64 instruction per SIMD\",\n \"cyc\": {\n";
 	const int maxblk = cus * 4 * 4;
@@ -177,15 +179,15 @@ int main(int argc, char **argv)
 			CK(hipMemcpy(h.data(), st, nblk * 2 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
 			std::vector<double> cyc(nblk), ghz(nblk);
 			for (int b = 0; b < nblk; ++b) {
-				cyc[b] = (double)h[2 * b] * w / ((double)ITERS * 64);
+				cyc[b] = (double)h[2 * b] / ((double)ITERS * 64);
 				ghz[b] = h[2 * b + 1] ? (double)h[2 * b] / (double)h[2 * b + 1] * 0.1 : 0.0;
 			}
 			std::sort(cyc.begin(), cyc.end()); std::sort(ghz.begin(), ghz.end());
 			const double c = cyc[nblk / 2], g = ghz[nblk / 2];
 			const double wall = ms * 1e-3 * g * 1e9 / ((double)ITERS * 64 * w);   /* cycles per instruction per SIMD from wall time */
-			printf("  %8.2f %5.2f %5.2f", c, g, wall);
+			printf("  %8.2f %5.2f %5.2f", c, wall, g);
 			char buf[96];
-			snprintf(buf, sizeof buf, "%s\"%d\": %.3f", wi ? ", " : "", w, c);
+			snprintf(buf, sizeof buf, "%s\"%d\": %.3f", wi ? ", " : "", w, wall);
 			js += buf;
 			if (wi == 3) { snprintf(buf, sizeof buf, ", \"ghz\": %.3f", g); js += buf; }
 		}

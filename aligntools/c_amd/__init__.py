@@ -15,7 +15,7 @@ import os
 import numpy as np
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "libaligntools_hip.so")
+LIB_PATH = os.environ.get("AT_LIB_PATH") or os.path.join(HERE, "libaligntools_hip.so")   # (AT_LIB_PATH: A/B builds, tools/)
 
 MODE_GLOBAL, MODE_LOCAL, MODE_FIT, MODE_OVERLAP, MODE_EDIT = 0, 1, 2, 3, 4
 MODES = {"global": MODE_GLOBAL, "local": MODE_LOCAL, "fit": MODE_FIT, "overlap": MODE_OVERLAP, "edit": MODE_EDIT}

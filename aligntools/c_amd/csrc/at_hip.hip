@@ -405,7 +405,7 @@ static int ensure_sitemask(at_handle *h, int max_l2, hipStream_t stream)
  * Work is handed out through an atomic counter, so the grid only has to cover the waves that
  * can be resident; over-estimating it is harmless. */
 struct Plan {
-	int store, off_ptr, off_extra;   /* off_extra: LDS word offset of the caller's extra block (walk states) */
+	int store, off_ptr;
 	long long grid, slot_words;
 	size_t dyn_lds;
 	uint32_t *ws;
@@ -435,11 +435,10 @@ static int choose_store(long long words_fixed, long long words_ptr, bool prefer_
 
 static int plan_launch(at_handle *h, const char *tag, int k, long long nwork, long long words_fixed, long long words_ptr,
                        Plan *pl, hipStream_t stream, const std::function<const void *(int)> &kernel_for_store,
-                       bool prefer_hbm_pointers = false, int slots_per_wave = 1, int extra_lds_words = 0)
+                       bool prefer_hbm_pointers = false)
 {
 	const int store = choose_store(words_fixed, words_ptr, prefer_hbm_pointers);
-	const long long lds_base = store == 0 ? words_fixed + words_ptr : (store == 1 ? words_fixed : 0);
-	const long long lds_words = lds_base + extra_lds_words;
+	const long long lds_words = store == 0 ? words_fixed + words_ptr : (store == 1 ? words_fixed : 0);
 	const long long slot_words = store == 0 ? 0 : (((store == 1 ? words_ptr : words_fixed + words_ptr) + 63) & ~63LL);
 	long long per_cu = 16;
 	if (lds_words > 0) per_cu = std::min<long long>(per_cu, (long long)(h->lds_per_cu - 512) / std::max<long long>(lds_words * 4, 256));
@@ -455,17 +454,15 @@ static int plan_launch(at_handle *h, const char *tag, int k, long long nwork, lo
 	 * waves cost 5-13 % more than the partial last round they avoid.) */
 	pl->store = store;
 	pl->off_ptr = store == 1 ? 0 : (int)words_fixed;
-	pl->off_extra = (int)((lds_base + 3) & ~3LL);   /* 16-byte aligned (the 4 words of slack are in extra_lds_words) */
 	pl->dyn_lds = (size_t)lds_words * 4;
 	pl->slot_words = slot_words;
 	pl->ws = nullptr;
 	if (slot_words > 0) {
 		const long long cap = env_ll("AT_WS_CAP_MB", 16384) << 20;
 		if (slot_words * 4 > cap) return fail(h, AT_ERR_NOMEM, "one pair needs %lld workspace bytes (cap %lld)", slot_words * 4, cap);
-		/* (the packed kernels with deferred tracebacks alternate between two slots per wave, at_sweep16.hip.h PIPE) */
-		grid = std::max(1LL, std::min(grid, cap / (slot_words * 4 * slots_per_wave)));
+		grid = std::max(1LL, std::min(grid, cap / (slot_words * 4)));
 		void *p = h->d_ws; size_t have = h->ws_bytes;
-		int rc = grow(h, &p, &have, (size_t)(grid * slot_words * 4 * slots_per_wave));
+		int rc = grow(h, &p, &have, (size_t)(grid * slot_words * 4));
 		h->d_ws = (uint32_t *)p; h->ws_bytes = have;
 		if (rc) return rc;
 		pl->ws = h->d_ws;
@@ -685,11 +682,9 @@ static int align_device(at_handle *h, int mode, int64_t npairs,
 		         rag ? " ragged frames" : "");
 		auto pick = [&](int st) { return rag ? at_pick16_rag(P.k, st, tb, bits) : at_pick16(kmode, P.g, P.k, ts, st, tb, bits); };
 		int rc = plan_launch(h, tag16, P.k, (npairs + per_wave - 1) / per_wave, P.off_ptr, P.words - P.off_ptr, &pl, stream,
-		                     [&](int st) { return (const void *)pick(st); }, P.g < 64,
-		                     tb && (kmode == at::K_FIT || kmode == at::K_FITJ) ? 2 : 1 /* deferred tracebacks: two slots per wave */, tb ? 128 + 4 : 0);
+		                     [&](int st) { return (const void *)pick(st); }, P.g < 64);
 		if (rc) return rc;
 		b.off_ptr = pl.off_ptr; b.ws = pl.ws; b.ws_slot_words = pl.slot_words; b.queue = h->d_queue;
-		b.off_wk = pl.off_extra;           /* 16-byte aligned: the walk states are read and written 4 words at a time */
 		at_sweep16_fn fn16 = pick(pl.store);
 		if (!fn16 || (P.g != 64 && pl.store == 2)) return fail(h, AT_ERR_RANGE, "no packed kernel for this shape (rows/lane=%d, store=%d)", P.k, pl.store);
 		if (pl.dyn_lds > 48 * 1024)

@@ -56,7 +56,6 @@ struct Sweep16Args {
 	uint32_t *ws;
 	long long ws_slot_words;
 	int off_refb, off_bound, off_ptr, off_sm, nsm;   /* off_sm/nsm: site mask words staged behind the boundary row */
-	int off_wk;                    /* LDS word offset of the walk states (64 words; kernels with tracebacks) */
 	int ptr_lanes;
 	unsigned long long *queue;     /* work counter, zeroed before every launch */
 	/* RAG kernels (local, ragged batch): l1 / l2 are the FRAME every work item is swept in, len1 / len2 the pairs' own
@@ -160,6 +159,13 @@ AT_DEV uint32_t grp_up1(uint32_t old, uint32_t src)
  * narrower group of their own): a lane stores 16 bytes at once (about K / 4 stores per block instead of K, each covering
  * 1 KiB of consecutive addresses), and a 128-byte line holds 8 lanes x 4 rows, so a pointer walk, which climbs one row
  * per op, finds up to four ops in a line instead of a new line per op.  NL is a multiple of 4 (16-byte alignment). */
+/* bit offset of step `sw` of a pointer word inside its 16-bit half (see the assembly of acc[] in the step body) */
+template <int PB>
+AT_DEV int cell_shift(int sw)
+{
+	return PB == 8 ? 8 * sw : 8 * (sw & 1) + 4 * (sw >> 1);
+}
+
 template <bool LDS, int K>
 AT_DEV int pidx(int wr, int r, int lane, int NL)
 {
@@ -197,23 +203,13 @@ __global__ __launch_bounds__(64, AT_WAVES16(G, K)) void at_sweep16(const Sweep16
 	constexpr bool ONEBODY = G <= 16;
 	constexpr int RPB = BLK / SPW;            /* pointer word rows per block */
 	constexpr int RS = G * K;                 /* rows per strip (G < 64: the only strip) */
-	/* Deferred tracebacks (pointer matrix in the global slot): the pointer walks of work item n run INSIDE the sweep of
-	 * work item n+1 of the same wave, one op per sweep step, each op's pointer word loaded one step ahead -- the walks'
-	 * dependent HBM loads (hundreds of them for fit / global) then cost the wave no idle time of its own.  The sweep of
-	 * item n+1 must not overwrite the pointers item n's walks still read: a wave owns TWO slots and alternates.
-	 * Used for the fit modes, whose walks cross the whole read (C4: the waves of a SIMD otherwise sit in their walks at
-	 * the same time for a fifth of the run; 1 617 -> 1 785 GCUPS).  Local and global batches already run at the VALU
-	 * issue bound with the walks where they are, and the per-step bookkeeping of deferring them costs 7-8 % there. */
-	constexpr bool PIPE = TB && !PTRLDS && (MODE == K_FIT || MODE == K_FITJ);
 	constexpr int PADW = kPad / 4;            /* s2 bytes: 4 per word */
 	const int lane = threadIdx.x;
 	const int grp = lane / G, lg = lane % G;
 	Slot<SMALL> mem;
-	uint32_t *const slot0 = a.ws + (long long)blockIdx.x * (PIPE ? 2 : 1) * a.ws_slot_words;
-	mem.g = SMALL ? nullptr : slot0;
-	PtrStore<PTRLDS> pm, pr;                  /* pm: the slot this sweep writes; pr: the slot the pending walks read */
-	pm.g = PTRLDS ? nullptr : slot0;
-	pr.g = pm.g;
+	mem.g = SMALL ? nullptr : a.ws + (long long)blockIdx.x * a.ws_slot_words;
+	PtrStore<PTRLDS> pm;
+	pm.g = PTRLDS ? nullptr : a.ws + (long long)blockIdx.x * a.ws_slot_words;
 	const int l1 = a.l1, l2 = a.l2, NL = a.ptr_lanes;
 	const int o16 = a.o16, e16 = a.e16;
 	uint32_t o2 = pk2(a.o16), e2 = pk2(a.e16);
@@ -223,16 +219,15 @@ __global__ __launch_bounds__(64, AT_WAVES16(G, K)) void at_sweep16(const Sweep16
 	/* constants live in VGPRs: VOP3 encodings take no 32-bit literals, and a literal would split and_or into two ops */
 	uint32_t cClean = (uint32_t)(0xffff & ~TMASK) * 0x00010001u, cTagM = (uint32_t)TGM * 0x00010001u;
 	uint32_t cTagL = (uint32_t)TGL * 0x00010001u, cTagU = (uint32_t)TGU * 0x00010001u;
-	uint32_t cM3 = 0x00030003u, cM7 = 0x00070007u, cNib = 0x000f000fu;
-	uint32_t c8 = TS == 4 ? 0x00080008u : 0x00020002u;   /* the bit of the J winner's tag that tells M (open) from J */
+	uint32_t cM3 = 0x00030003u, cM7 = 0x00070007u, cNib = 0x000f000fu, cF0 = 0x00f000f0u, cF000 = 0xf000f000u;
 	/* jump state: J(i,j) = max(M(i,j-1) + g, J(i,j-1)) where the column may open, else J(i,j-1) (alignment.h:658-666);
 	 * the left state holds M + o, so the opening candidate is (M + o) + (g - o), or -inf where opening is barred */
 	uint32_t gmo2 = pk2(a.g16 - a.o16), neg2 = 0x80008000u;
-	asm volatile("" : "+v"(c8), "+v"(gmo2), "+v"(neg2));
+	asm volatile("" : "+v"(gmo2), "+v"(neg2));
 	uint32_t c1 = 0x00010001u, umm2 = pk2(a.u16 - a.m16), m2 = pk2(a.m16);   /* 8-bit alphabets: compare instead of LUT */
 	asm volatile("" : "+v"(c1), "+v"(umm2), "+v"(m2));
 	asm volatile("" : "+v"(o2), "+v"(e2), "+v"(lut_lo), "+v"(lut_hi));
-	asm volatile("" : "+v"(cClean), "+v"(cTagM), "+v"(cTagL), "+v"(cTagU), "+v"(cM3), "+v"(cM7), "+v"(cNib));
+	asm volatile("" : "+v"(cClean), "+v"(cTagM), "+v"(cTagL), "+v"(cTagU), "+v"(cM3), "+v"(cM7), "+v"(cNib), "+v"(cF0), "+v"(cF000));
 	const int nstrips = (l1 + RS - 1) / RS;   /* host guarantees 1 when G < 64 */
 	const int tbk = (l2 + G - 1 + BLK - 1) / BLK;
 	const int wps = tbk * RPB * K;            /* pointer word rows per strip */
@@ -243,104 +238,10 @@ __global__ __launch_bounds__(64, AT_WAVES16(G, K)) void at_sweep16(const Sweep16
 
 	if (a.only_if && __builtin_amdgcn_readfirstlane(*a.only_if) != a.only_val) return;
 
-	/* ---- pointer walks (trace_back_*: alignment.h:372-412, 558-592, 766-800), one per lane so that the walks of a work
-	 *      item overlap: lane q < 2*NG walks alignment q = 2*group + half.  A walk is a small state machine advanced one
-	 *      op per walk_tick(); the pointer word of the cell it stands on is loaded one tick ahead (wkpend).  Its state
-	 *      lives in LDS (8 words per walker lane at a.off_wk), not in registers: with deferred tracebacks it is alive
-	 *      across the whole sweep of the next work item, whose unrolled step body needs every VGPR it can get.
-	 *      words: 0 ci, 1 cj, 2 {st (3 LOW, 2 MID, 1 UPP, 0 JUMP/HOME; 0xff: no walk pending), ok << 8, shift << 16},
-	 *             3 ops written so far, 4-5 the ops slot, 6-7 the pair index ---- */
-	uint32_t wkpend = 0;                   /* pointer word of the cell the walk stands on */
-	bool walking = false;                  /* wave-uniform: some lane has a walk pending */
-	const int wko = a.off_wk + (lane & 15) * 8;   /* (at most 16 walker lanes: 8 groups of 8 lanes) */
-	const bool walker = lane < 2 * NG;
-	const int wglane = (lane >> 1) * G;    /* lane 0 of the group whose alignment this lane walks */
-	const int wh = lane & 1;
-	/* one more pointer cell to read, or done: padding ops, count (called at the start and after every op) */
-	auto walk_next = [&](int &ci, int &cj, int &st, int &cnt, bool &ok, int &sh, uint8_t *ops, long long p) {
-		bool more = ok && ci > 0 && (ISFIT || cj > 0) && !(MODE == K_LOCAL && st == 0);   /* HOME :788-791 */
-		if (more && (cj <= 0 || cnt >= l1 + l2)) { ok = false; more = false; }
-		if (more) {
-			const int ss = G == 64 ? (ci - 1) / RS : 0, li = G == 64 ? (ci - 1) % RS : ci - 1;
-			const int ln = li / K, r = li % K;
-			const int t = (cj - 1) + ln;
-			sh = 16 * wh + PB * (SPW - 1 - (t % SPW));
-			wkpend = pr.ld(a.off_ptr + ss * wps * NL + pidx<PTRLDS, K>(t / SPW, r, wglane + ln, NL));
-		} else {
-			if constexpr (MODE == K_GLOBAL) {                 /* padding loops :398-407 */
-				if (ok) {
-					while (cj > 0) { ops[cnt++] = 2; --cj; }
-					while (ci > 0) { ops[cnt++] = 1; --ci; }
-				}
-			}
-			if (a.nops) a.nops[p] = ok ? cnt : -1;
-			if (!ok) a.score[p] = INT32_MIN;
-			st = -1;
-		}
-	};
-	auto walk_op = [&](int &ci, int &cj, int &st, int &cnt, bool &ok, int &sh, uint8_t *ops, long long p) {
-		/* nibble {bit 3: U winner, bit 2: L winner, pM[1:0]} (+ bit 4: J came from M).  Bit 3 is bit 3 of the
-		 * winner's tag for TS = 4 (M's 10 has it) and bit 0 for TS = 2 (U's 1 has it). */
-		const uint32_t nb = (wkpend >> sh) & ((1u << PB) - 1u);
-		const bool l_ext = (nb & 4u) != 0;
-		const bool u_open = TS == 4 ? (nb & 8u) != 0 : (nb & 8u) == 0;
-		const bool j_open = (nb & 16u) != 0;
-		int op = 0;
-		if (st == 3) { st = l_ext ? 3 : 2; op = 1; --ci; }
-		else if (st == 2) { st = (int)(nb & 3u); op = 0; --ci; --cj; }
-		else if (st == 1) { st = u_open ? 2 : 1; op = 2; --cj; }
-		else if (HASJ) { st = j_open ? 2 : 0; op = 3; --cj; }       /* jump state :579-583 */
-		else ok = false;
-		if (ok) ops[cnt++] = (uint8_t)op;
-		walk_next(ci, cj, st, cnt, ok, sh, ops, p);
-	};
-	auto walk_store = [&](int ci, int cj, int st, int cnt, bool ok, int sh) {
-		*reinterpret_cast<uint4 *>(&at_lds[wko]) = make_uint4((uint32_t)ci, (uint32_t)cj, ((uint32_t)st & 0xffu) | (ok ? 0x100u : 0u) | ((uint32_t)sh << 16), (uint32_t)cnt);
-	};
-	auto walk_tick = [&]() {               /* deferred mode: one op of every pending walk */
-		bool act = false;
-		if (walker) {
-			const uint4 s0 = *reinterpret_cast<const uint4 *>(&at_lds[wko]);
-			int st = (int)(int8_t)(s0.z & 0xffu);
-			if (st >= 0) {
-				const uint4 s1 = *reinterpret_cast<const uint4 *>(&at_lds[wko + 4]);
-				uint8_t *ops = reinterpret_cast<uint8_t *>(((unsigned long long)s1.y << 32) | s1.x);
-				const long long p = (long long)(((unsigned long long)s1.w << 32) | s1.z);
-				int ci = (int)s0.x, cj = (int)s0.y, cnt = (int)s0.w, sh = (int)(s0.z >> 16);
-				bool ok = (s0.z & 0x100u) != 0;
-				walk_op(ci, cj, st, cnt, ok, sh, ops, p);
-				walk_store(ci, cj, st, cnt, ok, sh);
-				act = st >= 0;
-			}
-		}
-		walking = __any(act);
-	};
-	/* start the walk of alignment `lane` of a work item from its end cell and leave it pending */
-	auto walk_start = [&](bool mine, long long p, int ci, int cj, int st, bool ok) {
-		int cnt = 0, sh = 0;
-		uint8_t *ops = nullptr;
-		if (mine) {
-			ops = a.ops + a.ops_off[p];
-			walk_next(ci, cj, st, cnt, ok, sh, ops, p);
-		} else st = -1;
-		if (walker) {
-			if (mine)
-				*reinterpret_cast<uint4 *>(&at_lds[wko + 4]) = make_uint4((uint32_t)(unsigned long long)ops, (uint32_t)((unsigned long long)ops >> 32),
-				                                                          (uint32_t)(unsigned long long)p, (uint32_t)((unsigned long long)p >> 32));
-			walk_store(ci, cj, st, cnt, ok, sh);
-		}
-		walking = __any(st >= 0);
-	};
-
-	int par = 0;                           /* PIPE: which of the wave's two slots the next sweep writes */
 	long long wnext = blockIdx.x;
 	while (wnext < nwork) {
 		const long long wk = wnext;
 		wnext = next_work(a.queue, lane);   /* consumed at the end of this work item: latency hidden */
-		if constexpr (PIPE) {
-			pm.g = slot0 + par * a.ws_slot_words;
-			if constexpr (!SMALL) mem.g = pm.g;
-		}
 		const long long last = a.npairs - 1;
 		long long pA = (wk * NG + grp) * 2 < a.npairs ? (wk * NG + grp) * 2 : last;
 		long long pB = (wk * NG + grp) * 2 + 1 < a.npairs ? (wk * NG + grp) * 2 + 1 : last;
@@ -434,7 +335,7 @@ __global__ __launch_bounds__(64, AT_WAVES16(G, K)) void at_sweep16(const Sweep16
 				/* my query bases of both alignments as the bytes {qB|4, qB, qA|4, qA}: xor-ing the s2 bytes {b,b,a,a}
 				 * onto it gives the LUT selector directly (codes are < 4, so the |4 survives the xor) */
 				qsel[r] = (ca * 0x00000101u + cb * 0x01010000u) | (BITS == 2 ? 0x04000400u : 0u);
-				acc[r] = 0;
+				acc[r] = 0;                       /* (steps outside the matrix leave their bits as they are: never read) */
 				/* rows past l1 (only in the last lane that owns rows): their key collapses to the bare row tag,
 				 * which every real row of the lane beats (smaller r = larger tag, score >= 0) */
 				keymask[r] = (i0 + r < l1A ? (uint32_t)(0xffff & ~TMASK) : 0u) | (i0 + r < l1B ? (uint32_t)(0xffff & ~TMASK) << 16 : 0u);
@@ -558,29 +459,27 @@ __global__ __launch_bounds__(64, AT_WAVES16(G, K)) void at_sweep16(const Sweep16
 							}
 							const uint32_t Ld = pmax(padd(Lc, e2), Mo);
 							if constexpr (TB) {
+								/* the cell's pointer bits, in the low bits of each 16-bit half (what lies above them is junk
+								 * until the word is assembled): [1:0] pM, bit 2: L extended, bit 3: U extended, bit 4: J opened */
+								uint32_t c;
 								if constexpr (TS == 4) {
-									uint32_t nib = vbfi(cM3, Mraw, lraw);
-									nib = vbfi(cM7, nib, Uraw);
-									if constexpr (HASJ) {
-										/* 5 bits: the nibble plus bit 4 = J came from M; two steps per 16-bit half */
-										nib = ((Jraw & c8) << 1) | (nib & cNib);
-										acc[r] = pshl8(acc[r]) | nib;
-									} else {
-										/* each half keeps its own 4-step shift register: acc = acc << 4 | nibble */
-										acc[r] = vandor(nib, cNib, pshl4(acc[r]));
-									}
+									/* tags L 15 / M 10 / U 1: the L winner is 1111 (ext) or 1010 (open), the U winner 1010 (open) or
+									 * 0001 (ext); their xor has bit 2 = L extended, bit 3 = U extended */
+									c = vbfi(cM3, Mraw, lraw ^ Uraw);
 								} else {
-									/* 2-bit tags: bit 0 of the L winner (3 ext / 2 open) and of the U winner (1 ext / 2 open)
-									 * carry the choice: nibble = {U tag bit 0, L tag bit 0, pM[1:0]} (+ bit 4: J tag bit 1) */
-									uint32_t nib = vbfi(cM3, Mraw, pshln<2>(lraw));
-									nib = vbfi(cM7, nib, pshln<3>(Uraw));
-									if constexpr (HASJ) {
-										nib = ((Jraw & c8) << 3) | (nib & cNib);
-										acc[r] = pshl8(acc[r]) | nib;
-									} else {
-										acc[r] = vandor(nib, cNib, pshl4(acc[r]));
-									}
+									/* 2-bit tags: bit 0 of the L winner (3 ext / 2 open) and of the U winner (1 ext / 2 open) */
+									c = vbfi(cM7, vbfi(cM3, Mraw, pshln<2>(lraw)), pshln<3>(Uraw));
 								}
+								if constexpr (HASJ) c = vbfi(cNib, c, pshln<TS == 4 ? 1 : 3>(Jraw));   /* J winner's tag: M's (open) or 0 */
+								/* assembling the word of SPW steps costs 1.25 instructions per step (4-bit cells) or 0.5 (8-bit cells)
+								 * instead of a mask and a shift-or per step: bytes are gathered with v_perm, which does not care what
+								 * the unused bits of a byte hold; half h of the word: 8-bit cells [step 1 | step 0], 4-bit cells
+								 * [step 3 | step 1 | step 2 | step 0] (nibbles, most significant first) */
+								constexpr int sw = k % SPW;
+								if constexpr (sw == 0) acc[r] = c;
+								else if constexpr (sw == 1) acc[r] = __builtin_amdgcn_perm(c, acc[r], 0x06020400u);
+								else if constexpr (sw == 2) acc[r] = vbfi(cF0, pshln<4>(c), acc[r]);
+								else acc[r] = vbfi(cF000, pshln<12>(c), acc[r]);
 							}
 							if constexpr (MODE == K_LOCAL) {
 								uint32_t rt = (uint32_t)(TMASK - r % CS) * 0x00010001u;
@@ -614,17 +513,7 @@ __global__ __launch_bounds__(64, AT_WAVES16(G, K)) void at_sweep16(const Sweep16
 						A_prev = up; B_prev = lraw;
 						if (wb && lane == 63) mem.st2(a.off_bound + 2 * (jm1 + 1), up, lraw);
 					}
-					else if constexpr (TB && masked) {
-						/* keep the shift registers in step: nibble k of a word is always step k of its 4-step group.
-						 * (Xl needs nothing here: a lane is active for one contiguous run of steps, both copies start out
-						 * holding the column-0 values, and nothing is read after the run.) */
-#pragma unroll
-						for (int r = 0; r < K; ++r) acc[r] = PB == 8 ? pshl8(acc[r]) : pshl4(acc[r]);
-					}
 					Ad = Aup;
-					if constexpr (PIPE) {
-						if (walking) walk_tick();   /* the previous work item's walks: one op per sweep step */
-					}
 					if constexpr (TB) {
 						if ((k + 1) % SPW == 0 && lane < NL) {
 							if constexpr (PTRLDS) {
@@ -730,26 +619,55 @@ __global__ __launch_bounds__(64, AT_WAVES16(G, K)) void at_sweep16(const Sweep16
 			const long long pin = (wk * NG + g) * 2 + h;          /* = wk * 2 * NG + lane */
 			const bool mine = lane < 2 * NG && pin < a.npairs;
 			const long long p = RAG ? pout : pin;                  /* RAG: the host's order array says which pair this is */
-			if constexpr (PIPE) {
-				/* deferred: the results go out now, the walk is left pending for the next sweep's steps */
-				if (mine) {
-					a.score[p] = my_ok ? (my_sc >> TS) : INT32_MIN;
-					if (a.end_i) a.end_i[p] = my_ci;
-					if (a.end_j) a.end_j[p] = my_cj;
-					if (a.state) a.state[p] = my_st == 3 ? 1 : my_st == 2 ? 2 : 3;
-				}
-				while (walking) walk_tick();                       /* (walks that outlasted this sweep) */
-				pr.g = pm.g;                                       /* the new walks read the slot just written ... */
-				par ^= 1;                                          /* ... while the next sweep fills the other one */
-				walk_start(mine, p, my_ci, my_cj, my_st, my_ok);
-			} else if (mine) {
+			if (mine) {
 				int ci = my_ci, cj = my_cj, st = my_st, cnt = 0;
 				bool ok = my_ok;
 				if constexpr (TB) {
 					uint8_t *ops = a.ops + a.ops_off[p];
 					const int glane = g * G;
 					int guard = l1 + l2 + 2;
-					if (ok) {
+					if (ok && ISFIT) {
+						/* fit: the walk crosses the whole read, and with the jump state a run of JUMP ops crosses hundreds of
+						 * columns (C4: 380 ops per pair on average), every op a dependent load from HBM.  Runs are predictable:
+						 * while the state does not change the walk keeps its direction (LOW up, MID diagonal, UPP / JUMP left).
+						 * So the pointer words of the next four cells along the current direction are loaded together and
+						 * consumed while the state stays what it was: one round trip to HBM per run of four instead of one per op. */
+						constexpr int AHEAD = 4;
+						while (ci > 0) {
+							if (cj <= 0 || cnt >= l1 + l2) { ok = false; break; }   /* (a walk never has more ops than its slot holds) */
+							const int di = st >= 2 ? 1 : 0, dj = st == 3 ? 0 : 1;
+							uint32_t w[AHEAD];
+							int sh[AHEAD];
+#pragma unroll
+							for (int q = 0; q < AHEAD; ++q) {
+								const int qi = imax(ci - q * di, 1), qj = imax(cj - q * dj, 1);   /* (clamped cells are never consumed) */
+								const int ss = G == 64 ? (qi - 1) / RS : 0, li = G == 64 ? (qi - 1) % RS : qi - 1;
+								const int ln = li / K, r = li % K;
+								const int t = (qj - 1) + ln;
+								sh[q] = 16 * h + cell_shift<PB>(t % SPW);
+								w[q] = pm.ld(a.off_ptr + ss * wps * NL + pidx<PTRLDS, K>(t / SPW, r, glane + ln, NL));
+							}
+							bool go = true;
+#pragma unroll
+							for (int q = 0; q < AHEAD; ++q) {
+								if (go) {
+									const uint32_t nb = (w[q] >> sh[q]) & ((1u << PB) - 1u);
+									const int was = st;
+									int op = 0;
+									if (st == 3) { st = (nb & 4u) ? 3 : 2; op = 1; --ci; }
+									else if (st == 2) { st = (int)(nb & 3u); op = 0; --ci; --cj; }
+									else if (st == 1) { st = (nb & 8u) ? 1 : 2; op = 2; --cj; }
+									else if (HASJ) { st = (nb & 16u) ? 2 : 0; op = 3; --cj; }   /* jump state :579-583 */
+									else { ok = false; go = false; }
+									if (ok) {
+										ops[cnt++] = (uint8_t)op;
+										go = st == was && ci > 0 && cj > 0 && cnt < l1 + l2;   /* the next prefetched cell is the next cell */
+									}
+								}
+							}
+							if (!ok) break;
+						}
+					} else if (ok) {
 						while (ci > 0 && (ISFIT || cj > 0) && --guard >= 0) {
 							if (MODE == K_LOCAL && st == 0) break;            /* HOME :788-791 */
 							if (cj <= 0) { ok = false; break; }
@@ -757,12 +675,11 @@ __global__ __launch_bounds__(64, AT_WAVES16(G, K)) void at_sweep16(const Sweep16
 							const int ln = li / K, r = li % K;
 							const int t = (cj - 1) + ln;
 							const uint32_t w = pm.ld(a.off_ptr + ss * wps * NL + pidx<PTRLDS, K>(t / SPW, r, glane + ln, NL));
-							const uint32_t nb = (w >> (16 * h + PB * (SPW - 1 - (t % SPW)))) & ((1u << PB) - 1u);
+							const uint32_t nb = (w >> (16 * h + cell_shift<PB>(t % SPW))) & ((1u << PB) - 1u);
 							int op;
-							/* nibble {bit 3: U winner, bit 2: L winner, pM[1:0]} (+ bit 4: J came from M).  Bit 3 is bit 3 of the
-							 * winner's tag for TS = 4 (M's 10 has it) and bit 0 for TS = 2 (U's 1 has it). */
+							/* {bit 4: J came from M, bit 3: U extended, bit 2: L extended, pM[1:0]} */
 							const bool l_ext = (nb & 4u) != 0;
-							const bool u_open = TS == 4 ? (nb & 8u) != 0 : (nb & 8u) == 0;
+							const bool u_open = (nb & 8u) == 0;
 							const bool j_open = (nb & 16u) != 0;
 							if (st == 3) { st = l_ext ? 3 : 2; op = 1; --ci; }
 							else if (st == 2) { st = (int)(nb & 3u); op = 0; --ci; --cj; }
@@ -787,7 +704,6 @@ __global__ __launch_bounds__(64, AT_WAVES16(G, K)) void at_sweep16(const Sweep16
 		}
 		mem.sync();
 	}
-	if constexpr (PIPE) { while (walking) walk_tick(); }
 }
 
 } /* namespace at */

@@ -460,12 +460,12 @@ __global__ __launch_bounds__(64, AT_WAVES16(G, K)) void at_sweep16(const Sweep16
 							const uint32_t Ld = pmax(padd(Lc, e2), Mo);
 							if constexpr (TB) {
 								/* the cell's pointer bits, in the low bits of each 16-bit half (what lies above them is junk
-								 * until the word is assembled): [1:0] pM, bit 2: L extended, bit 3: U extended, bit 4: J opened */
+								 * until the word is assembled): [1:0] pM, bit 2: L extended, bit 3: the U winner's tag bit, bit 4: J opened */
 								uint32_t c;
 								if constexpr (TS == 4) {
-									/* tags L 15 / M 10 / U 1: the L winner is 1111 (ext) or 1010 (open), the U winner 1010 (open) or
-									 * 0001 (ext); their xor has bit 2 = L extended, bit 3 = U extended */
-									c = vbfi(cM3, Mraw, lraw ^ Uraw);
+									/* tags L 15 / M 10 / U 1: bit 2 of the L winner (1111 ext / 1010 open), bit 3 of the U winner
+									 * (1010 open / 0001 ext).  (Not their xor: a saturated -inf carries no tag at all.) */
+									c = vbfi(cM7, vbfi(cM3, Mraw, lraw), Uraw);
 								} else {
 									/* 2-bit tags: bit 0 of the L winner (3 ext / 2 open) and of the U winner (1 ext / 2 open) */
 									c = vbfi(cM7, vbfi(cM3, Mraw, pshln<2>(lraw)), pshln<3>(Uraw));
@@ -656,7 +656,7 @@ __global__ __launch_bounds__(64, AT_WAVES16(G, K)) void at_sweep16(const Sweep16
 									int op = 0;
 									if (st == 3) { st = (nb & 4u) ? 3 : 2; op = 1; --ci; }
 									else if (st == 2) { st = (int)(nb & 3u); op = 0; --ci; --cj; }
-									else if (st == 1) { st = (nb & 8u) ? 1 : 2; op = 2; --cj; }
+									else if (st == 1) { st = (TS == 4 ? (nb & 8u) != 0 : (nb & 8u) == 0) ? 2 : 1; op = 2; --cj; }
 									else if (HASJ) { st = (nb & 16u) ? 2 : 0; op = 3; --cj; }   /* jump state :579-583 */
 									else { ok = false; go = false; }
 									if (ok) {
@@ -677,9 +677,10 @@ __global__ __launch_bounds__(64, AT_WAVES16(G, K)) void at_sweep16(const Sweep16
 							const uint32_t w = pm.ld(a.off_ptr + ss * wps * NL + pidx<PTRLDS, K>(t / SPW, r, glane + ln, NL));
 							const uint32_t nb = (w >> (16 * h + cell_shift<PB>(t % SPW))) & ((1u << PB) - 1u);
 							int op;
-							/* {bit 4: J came from M, bit 3: U extended, bit 2: L extended, pM[1:0]} */
+							/* {bit 4: J came from M, bit 3: U winner, bit 2: L extended, pM[1:0]}.  Bit 3 is bit 3 of the U winner's
+							 * tag for TS = 4 (M's 10 has it: opened) and bit 0 for TS = 2 (U's 1 has it: extended). */
 							const bool l_ext = (nb & 4u) != 0;
-							const bool u_open = (nb & 8u) == 0;
+							const bool u_open = TS == 4 ? (nb & 8u) != 0 : (nb & 8u) == 0;
 							const bool j_open = (nb & 16u) != 0;
 							if (st == 3) { st = l_ext ? 3 : 2; op = 1; --ci; }
 							else if (st == 2) { st = (int)(nb & 3u); op = 0; --ci; --cj; }

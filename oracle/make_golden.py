@@ -17,6 +17,9 @@ Files written
     random_dna.jsonl      ACGT-only cases at the BASELINE shapes (150x150,
                           150x500, a few 1024x1024) -- long outputs as md5
     cli.jsonl             stdout/stderr/rc of the stock reference CLI
+    known_answers_big.jsonl   the two runs of the reference's own fixtures that need gigabytes in the reference
+                          (`fit -s test/tmp.fa`, 1 327 x 114 491: 7.3 GB; `global test/test_fit.fa`,
+                          257 x 33 733); written by `python oracle/make_golden.py --only big` (the default run leaves it alone)
 """
 import hashlib
 import json
@@ -110,6 +113,22 @@ def known_answers():
     out.append(case("fit", s1, s2, 2, -2, -5, -1, -10, True, sites, tag="test_fit -s (README.md:82)"))
     out.append(case("fit", s1, s2, 1, -2, -5, -1, -10, True, sites, tag="test_fit -s defaults"))
     out.append(case("fit", s1, s2, 2, -2, -5, -1, -10, True, [100], tag="test_fit -s, site list [100]"))
+    return out
+
+
+def known_answers_big():
+    """The runs of the reference's own inputs that take gigabytes there (`fit -s test/tmp.fa` is
+    1 327 x 114 491 = 7.3 GB of matrices, score 1327 and two 1 327-character strings)."""
+    out = []
+    tmp = read_fasta(f"{REF_TEST}/tmp.fa")
+    sites = [int(x) for x in tmp[1][1].split("|")]
+    s1, s2 = tmp[0][2], tmp[1][2]
+    out.append(case("fit", s1, s2, 1, -2, -5, -1, -10, True, sites, tag="tmp.fa fit -s (defaults)"))
+    assert out[-1]["score"] == 1327 and out[-1]["rlen"] == 1327, (out[-1]["score"], out[-1].get("rlen"))
+    out.append(case("fit", s1, s2, 2, -2, -5, -1, -10, True, sites, tag="tmp.fa fit -s -m 2"))
+    fit = read_fasta(f"{REF_TEST}/test_fit.fa")
+    out.append(case("global", fit[0][2], fit[1][2], 1, -2, -5, -1, tag="test_fit global (defaults)"))
+    out.append(case("global", fit[0][2], fit[1][2], 1, -1, -4, -1, tag="test_fit global -m 1 -u -1 -o -4 -e -1"))
     return out
 
 
@@ -255,6 +274,9 @@ def dump(name, rows):
 def main():
     assert O.have_ref(), "build oracle/_ref first (make -C oracle)"
     os.makedirs(OUT, exist_ok=True)
+    if sys.argv[1:3] == ["--only", "big"]:
+        dump("known_answers_big.jsonl", known_answers_big())
+        return
     dump("known_answers.jsonl", known_answers())
     dump("random_small.jsonl", random_small(random.Random(20261003), 1500))
     dump("random_dna.jsonl", random_dna(random.Random(7)))

@@ -57,7 +57,7 @@ def _run_group(al, key, cases):
         assert (gs["score"] == res["score"]).all() and (gs["nops"] == res["nops"]).all()
 
 
-@pytest.mark.parametrize("name", ["random_small.jsonl", "random_dna.jsonl", "known_answers.jsonl"])
+@pytest.mark.parametrize("name", ["random_small.jsonl", "random_dna.jsonl", "known_answers.jsonl", "known_answers_big.jsonl"])
 def test_hip_matches_reference_goldens(al, name):
     groups = _group(load_golden(name))
     for key, cases in groups.items():

@@ -88,14 +88,20 @@ extern "C" int at_init(const int *device_ids, int n_devices, at_handle **out)
 	if (dev < 0 || dev >= count) return fail(nullptr, AT_ERR_ARG, "at_init: device %d out of range (0..%d)", dev, count - 1);
 	at_handle *h = new at_handle();
 	h->device = dev;
-	HIP_TRY(h, hipSetDevice(dev));
-	hipDeviceProp_t prop;
-	HIP_TRY(h, hipGetDeviceProperties(&prop, dev));
-	h->ncu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
-	if (prop.maxSharedMemoryPerMultiProcessor > 0) h->lds_per_cu = prop.maxSharedMemoryPerMultiProcessor;
-	HIP_TRY(h, hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
-	HIP_TRY(h, hipMalloc((void **)&h->d_rflag, 256));
-	HIP_TRY(h, hipMemset(h->d_rflag, 0, 256));
+	/* a failing step frees what the earlier ones made: the caller gets no handle to destroy */
+	auto init = [&]() -> int {
+		HIP_TRY(h, hipSetDevice(dev));
+		hipDeviceProp_t prop;
+		HIP_TRY(h, hipGetDeviceProperties(&prop, dev));
+		h->ncu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+		if (prop.maxSharedMemoryPerMultiProcessor > 0) h->lds_per_cu = prop.maxSharedMemoryPerMultiProcessor;
+		HIP_TRY(h, hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
+		HIP_TRY(h, hipMalloc((void **)&h->d_rflag, 256));
+		HIP_TRY(h, hipMemset(h->d_rflag, 0, 256));
+		return AT_OK;
+	};
+	const int rc = init();
+	if (rc != AT_OK) { at_destroy(h); return rc; }   /* (the message is in the calling thread's at_last_error(NULL)) */
 	h->err[0] = 0;
 	*out = h;
 	return AT_OK;
@@ -181,6 +187,13 @@ extern "C" int at_pack_batch(int64_t npairs, const uint8_t *seq_blob,
 		}
 	}
 	if (bits != 2 && bits != 8) return fail(nullptr, AT_ERR_ARG, "at_pack_batch: bits must be 0, 2 or 8");
+	if (bits == 2) {   /* a caller that forces 2-bit words must hand over pure ACGT: there is no code for anything else */
+		for (int64_t k = 0; k < npairs; ++k) {
+			const uint8_t *a = seq_blob + off1[k], *b = seq_blob + off2[k];
+			for (int x = 0; x < len1[k]; ++x) if (code2(a[x]) < 0) return fail(nullptr, AT_ERR_ARG, "at_pack_batch: pair %lld: byte 0x%02x cannot be packed in 2 bits", (long long)k, a[x]);
+			for (int x = 0; x < len2[k]; ++x) if (code2(b[x]) < 0) return fail(nullptr, AT_ERR_ARG, "at_pack_batch: pair %lld: byte 0x%02x cannot be packed in 2 bits", (long long)k, b[x]);
+		}
+	}
 	if (bits_out) *bits_out = bits;
 	if (!words_out) return AT_OK;   /* query only */
 	const int bpw = 32 / bits;

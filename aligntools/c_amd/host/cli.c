@@ -82,23 +82,25 @@ static int main_single(int cmd, int argc, char *argv[])
 {
 	opt_t *opt = init_opt();
 	kstring_t *ks1, *ks2, *r1, *r2;
-	if (parse_opts(cmd, argc, argv, opt)) return 1;
-	if (optind + 1 > argc) { cmd_usage(cmd, opt); return 1; }
-	ks1 = (kstring_t *)calloc(1, sizeof(kstring_t));
-	ks2 = (kstring_t *)calloc(1, sizeof(kstring_t));
+	if (parse_opts(cmd, argc, argv, opt)) { free(opt); return 1; }
+	if (optind + 1 > argc) { cmd_usage(cmd, opt); free(opt); return 1; }
+	ks1 = (kstring_t *)at_xmalloc(sizeof(kstring_t)); memset(ks1, 0, sizeof *ks1);
+	ks2 = (kstring_t *)at_xmalloc(sizeof(kstring_t)); memset(ks2, 0, sizeof *ks2);
 	/* overlap reads argv[1], not argv[argc-1] (alignment.h:994): after getopt's permutation any
 	 * option makes that an option string -> "Can't open -m" */
 	kstring_read(cmd == C_OVERLAP ? argv[1] : argv[argc - 1], ks1, ks2, opt);
 	if (ks1->s == NULL || ks2->s == NULL) die("fail to read sequence\n");
 	if (cmd == C_EDIT) {
 		printf("edit_distance=%d\n", edit_dist(ks1, ks2, opt));
+		kstring_destory(ks1); kstring_destory(ks2);
+		free(opt->sites.pos); free(opt);
 		return 0;
 	}
 	if (cmd == C_FIT && ks1->l > ks2->l) die("first sequence must be shorter than the second\n");   /* :731 */
-	r1 = (kstring_t *)calloc(1, sizeof(kstring_t));
-	r2 = (kstring_t *)calloc(1, sizeof(kstring_t));
-	r1->s = (char *)calloc(ks1->l + ks2->l + 1, 1);
-	r2->s = (char *)calloc(ks1->l + ks2->l + 1, 1);
+	r1 = (kstring_t *)at_xmalloc(sizeof(kstring_t)); memset(r1, 0, sizeof *r1);
+	r2 = (kstring_t *)at_xmalloc(sizeof(kstring_t)); memset(r2, 0, sizeof *r2);
+	r1->s = (char *)at_xmalloc(ks1->l + ks2->l + 1); memset(r1->s, 0, ks1->l + ks2->l + 1);
+	r2->s = (char *)at_xmalloc(ks1->l + ks2->l + 1); memset(r2->s, 0, ks1->l + ks2->l + 1);
 	switch (cmd) {
 	case C_GLOBAL: printf("score=%f\n", align_gla(ks1, ks2, r1, r2, opt)); break;
 	case C_LOCAL: printf("score=%f\n", align_local_affine(ks1, ks2, r1, r2, opt)); break;
@@ -107,7 +109,7 @@ static int main_single(int cmd, int argc, char *argv[])
 	}
 	printf("%s\n%s\n", r1->s, r2->s);
 	kstring_destory(ks1); kstring_destory(ks2); kstring_destory(r1); kstring_destory(r2);
-	free(opt);
+	free(opt->sites.pos); free(opt);
 	return 0;
 }
 
@@ -123,11 +125,11 @@ static int main_batch(int argc, char *argv[])
 	char *r1, *r2;
 	int64_t *off1, *off2, *stroff;
 	int32_t *l1, *l2, *score, *ei, *ej, *st, *nops;
-	if (argc < 2) { fprintf(stderr, "Usage:   alignTools batch <global|local|fit|overlap|edit> [options] <pairs.fa>\n"); return 1; }
+	if (argc < 2) { fprintf(stderr, "Usage:   alignTools batch <global|local|fit|overlap|edit> [options] <pairs.fa>\n"); free(opt); return 1; }
 	for (k = 0; k < 5; ++k) if (strcmp(argv[1], cmd_name[k]) == 0) cmd = k;
-	if (cmd < 0) { fprintf(stderr, "[main] unrecognized command '%s'\n", argv[1]); return 1; }
-	if (parse_opts(cmd, argc - 1, argv + 1, opt)) return 1;
-	if (optind + 1 > argc - 1) { cmd_usage(cmd, opt); return 1; }
+	if (cmd < 0) { fprintf(stderr, "[main] unrecognized command '%s'\n", argv[1]); free(opt); return 1; }
+	if (parse_opts(cmd, argc - 1, argv + 1, opt)) { free(opt); return 1; }
+	if (optind + 1 > argc - 1) { cmd_usage(cmd, opt); free(opt); return 1; }
 	if (at_read_records(argv[argc - 1], &rec) != 0) die("Can't open %s\n", argv[argc - 1]);
 	if (rec.n < 2 || (rec.n & 1)) die("batch input needs an even number of records (got %d)", (int)rec.n);
 	n = rec.n / 2;
@@ -136,11 +138,11 @@ static int main_batch(int argc, char *argv[])
 		opt->sites.size = (size_t)at_parse_sites(rec.comment[1], &opt->sites.pos);
 	}
 	for (p = 0; p < rec.n; ++p) tot += rec.len[p];
-	blob = (uint8_t *)malloc(tot + 1);
-	r1 = (char *)malloc(tot + n + 64); r2 = (char *)malloc(tot + n + 64);
-	off1 = (int64_t *)malloc(n * 8); off2 = (int64_t *)malloc(n * 8); stroff = (int64_t *)malloc(n * 8);
-	l1 = (int32_t *)malloc(n * 4); l2 = (int32_t *)malloc(n * 4); score = (int32_t *)malloc(n * 4);
-	ei = (int32_t *)malloc(n * 4); ej = (int32_t *)malloc(n * 4); st = (int32_t *)malloc(n * 4); nops = (int32_t *)malloc(n * 4);
+	blob = (uint8_t *)at_xmalloc(tot + 1);
+	r1 = (char *)at_xmalloc(tot + n + 64); r2 = (char *)at_xmalloc(tot + n + 64);
+	off1 = (int64_t *)at_xmalloc(n * 8); off2 = (int64_t *)at_xmalloc(n * 8); stroff = (int64_t *)at_xmalloc(n * 8);
+	l1 = (int32_t *)at_xmalloc(n * 4); l2 = (int32_t *)at_xmalloc(n * 4); score = (int32_t *)at_xmalloc(n * 4);
+	ei = (int32_t *)at_xmalloc(n * 4); ej = (int32_t *)at_xmalloc(n * 4); st = (int32_t *)at_xmalloc(n * 4); nops = (int32_t *)at_xmalloc(n * 4);
 	tot = 0;
 	for (p = 0; p < n; ++p) {
 		off1[p] = (int64_t)tot; l1[p] = (int32_t)rec.len[2 * p];
@@ -162,6 +164,10 @@ static int main_batch(int argc, char *argv[])
 		if (cmd == C_EDIT) { printf("%s\t%s\tedit_distance=%d\n", rec.name[2 * p], rec.name[2 * p + 1], score[p]); continue; }
 		printf("%s\t%s\tscore=%f\n%s\n%s\n", rec.name[2 * p], rec.name[2 * p + 1], (double)score[p], r1 + stroff[p], r2 + stroff[p]);
 	}
+	free(blob); free(r1); free(r2); free(off1); free(off2); free(stroff);
+	free(l1); free(l2); free(score); free(ei); free(ej); free(st); free(nops);
+	at_free_records(&rec);
+	free(opt->sites.pos); free(opt);
 	return 0;
 }
 

@@ -141,8 +141,8 @@ void kstring_read(char *fname, kstring_t *str1, kstring_t *str2, opt_t *opt)
 	if (at_read_records(fname, &rec) != 0) die("Can't open %s\n", fname);
 	if (rec.n > 2) die("input fasta file has more than 2 sequences");
 	if (rec.n < 2) die("read_kstring: fail to read sequence");
-	str1->s = strdup(rec.seq[0]); str1->l = strlen(str1->s);
-	str2->s = strdup(rec.seq[1]); str2->l = strlen(str2->s);
+	str1->s = at_xstrdup(rec.seq[0]); str1->l = strlen(str1->s);
+	str2->s = at_xstrdup(rec.seq[1]); str2->l = strlen(str2->s);
 	if (opt->s == AT_TRUE) {
 		if (rec.comment[1] == NULL) die("fail to read junction sites");
 		printf("%s\n", rec.comment[1]);                                  /* :249 */

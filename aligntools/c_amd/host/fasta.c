@@ -22,6 +22,27 @@
 #include <string.h>
 #include <zlib.h>
 
+/* allocation failures end the process like the reference's mycalloc (alignment.h:81-87) */
+void *at_xmalloc(size_t n)
+{
+	void *p = malloc(n ? n : 1);
+	if (!p) die("mycalloc failure requesting %d of size %d bytes", (int)n, 1);
+	return p;
+}
+void *at_xrealloc(void *q, size_t n)
+{
+	void *p = realloc(q, n ? n : 1);
+	if (!p) die("mycalloc failure requesting %d of size %d bytes", (int)n, 1);
+	return p;
+}
+char *at_xstrdup(const char *s)
+{
+	size_t n = strlen(s) + 1;
+	char *p = (char *)at_xmalloc(n);
+	memcpy(p, s, n);
+	return p;
+}
+
 typedef struct {
 	gzFile f;
 	unsigned char buf[16384];
@@ -48,8 +69,7 @@ static void sput(sbuf *b, int c)
 {
 	if (b->l + 2 > b->m) {
 		b->m = b->m ? b->m * 2 : 256;
-		b->s = (char *)realloc(b->s, b->m);
-		if (!b->s) die("mycalloc failure requesting %d of size %d bytes", (int)b->m, 1);
+		b->s = (char *)at_xrealloc(b->s, b->m);
 	}
 	b->s[b->l++] = (char)c;
 	b->s[b->l] = 0;
@@ -114,14 +134,14 @@ int at_read_records(const char *fname, at_records *out)
 		}
 		if (out->n == cap) {
 			cap = cap ? cap * 2 : 4;
-			out->name = (char **)realloc(out->name, cap * sizeof(char *));
-			out->comment = (char **)realloc(out->comment, cap * sizeof(char *));
-			out->seq = (char **)realloc(out->seq, cap * sizeof(char *));
-			out->len = (size_t *)realloc(out->len, cap * sizeof(size_t));
+			out->name = (char **)at_xrealloc(out->name, cap * sizeof(char *));
+			out->comment = (char **)at_xrealloc(out->comment, cap * sizeof(char *));
+			out->seq = (char **)at_xrealloc(out->seq, cap * sizeof(char *));
+			out->len = (size_t *)at_xrealloc(out->len, cap * sizeof(size_t));
 		}
-		out->name[out->n] = strdup(name.s ? name.s : "");
-		out->comment[out->n] = comment.s ? strdup(comment.s) : NULL;   /* the shared-buffer quirk */
-		out->seq[out->n] = (char *)malloc(seq.l + 1);
+		out->name[out->n] = at_xstrdup(name.s ? name.s : "");
+		out->comment[out->n] = comment.s ? at_xstrdup(comment.s) : NULL;   /* the shared-buffer quirk */
+		out->seq[out->n] = (char *)at_xmalloc(seq.l + 1);
 		memcpy(out->seq[out->n], seq.s ? seq.s : "", seq.l);
 		out->seq[out->n][seq.l] = 0;
 		out->len[out->n] = seq.l;
@@ -146,12 +166,12 @@ void at_free_records(at_records *r)
 int at_parse_sites(const char *comment, int **pos_out)
 {
 	size_t l = strlen(comment), i, cap = 8;
-	int n = 0, *pos = (int *)calloc(cap, sizeof(int));
+	int n = 0, *pos = (int *)at_xmalloc(cap * sizeof(int));
 	i = 0;
 	while (i < l) {
 		while (i < l && comment[i] == '|') ++i;
 		if (i >= l) break;
-		if ((size_t)n == cap) { cap *= 2; pos = (int *)realloc(pos, cap * sizeof(int)); }
+		if ((size_t)n == cap) { cap *= 2; pos = (int *)at_xrealloc(pos, cap * sizeof(int)); }
 		pos[n++] = atoi(comment + i);
 		while (i < l && comment[i] != '|') ++i;
 	}

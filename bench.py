@@ -44,6 +44,34 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0   # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+PROFILE_ROUND = "r02"   # profiles/<round>/traffic_<workload>.json, valu_issue.json: the counters the roofline is priced with
+
+
+def valu_roofline(workload, pairs, tb, kernel_config, steps, elapsed):
+    """The binding roofline of this path is VALU issue (integer add/max on packed int16: no HBM or MFMA bound comes near,
+    DESIGN.md section 4).  achieved = SQ_INSTS_VALU of one launch (rocprofv3 --pmc on this workload and kernel
+    configuration, profiles/<round>/traffic_<W>[_scores].json) x launches / timed seconds; peak = SIMDs x clock / cycles per
+    wave64 instruction, both measured by tools/valu_issue.hip on the MI355X (profiles/<round>/valu_issue.json: the packed
+    16-bit, bit-field and DPP instructions the step body is made of occupy a SIMD for 4 cycles, and so does everything
+    else once it is mixed with them; the clock is what the chip held under that load, not the nominal 2.4 GHz)."""
+    try:
+        prof = json.load(open(os.path.join(ROOT, "profiles", PROFILE_ROUND, "traffic_%s%s.json" % (workload, "" if tb else "_scores"))))
+        vi = json.load(open(os.path.join(ROOT, "profiles", PROFILE_ROUND, "valu_issue.json")))
+    except Exception:
+        return None, None
+    insts = (prof.get("sq_counters_per_launch") or {}).get("SQ_INSTS_VALU")
+    traffic = prof.get("hbm_bytes_per_launch")
+    # the counters belong to one kernel configuration and batch size: another one (AT_GROUP, --pairs, --l1 ...) has no roofline
+    if not insts or prof.get("kernel_config") != kernel_config or prof.get("pairs") != pairs:
+        return None, traffic
+    cyc = vi["roofline"]["cycles_per_inst"]
+    ghz = vi["roofline"]["clock_ghz"]
+    simds = vi["roofline"]["simds"]
+    peak = simds * ghz / cyc                      # G wave-instructions / s
+    achieved = insts * steps / elapsed / 1e9
+    return dict(bound="valu", achieved=achieved, peak=peak, unit="G wave-instr/s", frac=achieved / peak,
+                valu_insts_per_launch=insts, cycles_per_inst=cyc, clock_ghz=ghz, simds=simds,
+                source="profiles/%s/traffic_%s%s.json + valu_issue.json" % (PROFILE_ROUND, workload, "" if tb else "_scores")), traffic
 
 WORKLOADS = {
     # name: (mode, l1, l2, pairs per GPU, scoring m,u,o,e,j, use_jump, sites, seed)
@@ -370,18 +398,7 @@ def main():
     bytes_in = words.nbytes + pairs * (8 + 8 + 4 + 4) + (pairs * 8 if tb else 0)
     bytes_out = pairs * 16 + (pairs * 4 + int(nops.sum()) if tb else 0)
     achieved = (bytes_in + bytes_out) / (kern_avg_ms * 1e-3) / 1e9
-    traffic = None
-    valu_frac = None
-    tpath = os.path.join(ROOT, "profiles", "traffic_%s.json" % args.workload)
-    if os.path.exists(tpath):
-        try:
-            prof = json.load(open(tpath))
-            traffic = prof.get("hbm_bytes_per_launch")
-            # VALU issue bound of the profiled launch (SQ_INSTS_VALU x measured cycles per instruction), live duration
-            if prof.get("valu_issue_bound_ms") and prof.get("valu_issue_bound_pairs") == pairs and tb:
-                valu_frac = prof["valu_issue_bound_ms"] / (elapsed / args.steps * 1e3)
-        except Exception:
-            traffic = None
+    valu, traffic = valu_roofline(args.workload, pairs, tb, al.last_config, args.steps, elapsed)
 
     if rank == 0:
         out = {
@@ -397,17 +414,17 @@ def main():
                        "pairs_per_gpu": pairs, "l1": l1, "l2": l2, "bits_per_base": bits, "kernel_config": al.last_config,
                        "streams": S,
                        "parallelism": "pairs sharded over %d GPU(s), one process per GPU" % world},
-            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                         "kernel": ("at_sweep16" if "packed16" in al.last_config else "at_sweep") + "<%s>" % mode,
-                         "kernel_avg_ms": kern_avg_ms,
-                         "kernel_min_ms": kern_ms[0], "kernel_alone_ms": kern_iso_ms, "launches_in_flight": S,
-                         "achieved_aggregate": (bytes_in + bytes_out) * args.steps / elapsed / 1e9,
-                         "algorithmic_bytes_per_launch": bytes_in + bytes_out,
-                         "note": "integer max/add DP: the binding resource is VALU issue, not HBM (DESIGN.md section 4; "
-                                 "profiles/traffic_C2.json holds the SQ counters and the issue-bound model)",
-                         "valu_gcups_kernel": float(pairs) * l1 * l2 / (kern_iso_ms * 1e-3) / 1e9,
-                         "valu_issue_frac": valu_frac},
+            "roofline": dict(valu or {"bound": "valu", "achieved": None, "peak": None, "unit": "G wave-instr/s", "frac": None,
+                                      "note": "no SQ_INSTS_VALU profile for this kernel configuration under profiles/%s" % PROFILE_ROUND},
+                             traffic=traffic,
+                             kernel=("at_sweep16" if "packed16" in al.last_config else "at_myers" if "myers" in al.last_config else "at_sweep") + "<%s>" % mode,
+                             kernel_avg_ms=kern_avg_ms, kernel_min_ms=kern_ms[0], kernel_alone_ms=kern_iso_ms, launches_in_flight=S,
+                             gcups_one_launch_at_a_time=float(pairs) * l1 * l2 / (kern_iso_ms * 1e-3) / 1e9,
+                             # the HBM view BASELINE.json asks for: ALGORITHMIC bytes of a launch over its HIP-event duration
+                             hbm={"achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                                  "achieved_aggregate": (bytes_in + bytes_out) * args.steps / elapsed / 1e9,
+                                  "algorithmic_bytes_per_launch": bytes_in + bytes_out,
+                                  "traffic_over_algorithmic": (traffic / float(bytes_in + bytes_out)) if traffic else None}),
             "cpu_baseline": base,
         }
         if gather_info:

@@ -34,6 +34,7 @@ static int host_only(void)
 	CHECK(at_pack_batch(1, blob, off1, len1, off2, len2, 2, NULL, words, w1, w2) == AT_OK);
 	CHECK((words[w1[0]] & 0xffffu) == 0xe4e4u);              /* ACGTACGT -> 0,1,2,3,0,1,2,3 */
 	CHECK(at_pack_batch(2, blob, off1, len1, off2, len2, 0, &bits, NULL, w1, w2) == AT_OK && bits == 8);
+	CHECK(at_pack_batch(2, blob, off1, len1, off2, len2, 2, NULL, words, w1, w2) == AT_ERR_ARG);   /* XYZ has no 2-bit code */
 	/* render: 3 diagonal steps ending at (6, 3) of LKSLEA / MEA */
 	CHECK(at_render(ops, 3, (const uint8_t *)"LKSLEA", 6, (const uint8_t *)"MEA", 3, r1, r2) == AT_OK);
 	CHECK(strcmp(r1, "LEA") == 0 && strcmp(r2, "MEA") == 0);

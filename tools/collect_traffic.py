@@ -42,7 +42,14 @@ def run_pass(workload, tag, counters, outdir, extra):
     for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
         with open(f) as fh:
             rows += list(csv.DictReader(fh))
-    return r.returncode, rows
+    line = None   # the bench line of the profiled run: which kernel configuration and batch size the counters belong to
+    for ln in r.stdout.splitlines():
+        if ln.startswith("{") and '"metric"' in ln:
+            try:
+                line = json.loads(ln)
+            except ValueError:
+                pass
+    return r.returncode, rows, line
 
 
 def per_kernel(rows):
@@ -69,7 +76,11 @@ def main():
                "--steps 3 --warmup 1 --no-render --no-cpu-baseline%s" % (w, " --no-traceback" if extra else ""),
                "passes": {}, "kernels": {}}
         for tag, counters in PASSES:
-            rc, rows = run_pass(w, tag, counters, args.out, extra)
+            rc, rows, line = run_pass(w, tag, counters, args.out, extra)
+            if line:
+                res["kernel_config"] = line["config"]["kernel_config"]
+                res["pairs"] = line["config"]["pairs_per_gpu"]
+                res["profiled_run_ms_per_step"] = line["ms_per_step"]
             res["passes"][tag] = {"rc": rc, "rows": len(rows), "counters": counters}
             pk = per_kernel(rows)
             for k, cs in pk.items():

@@ -164,6 +164,7 @@ int main(int argc, char **argv)
 	std::vector<unsigned long long> h(maxblk * 2);
 	hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
 	bool first = true;
+	std::vector<double> all_ghz, half_rate_cost;
 	for (const Entry &en : table) {
 		printf("%-26s", en.name);
 		js += std::string(first ? "" : ",\n") + "  \"" + en.name + "\": {";
@@ -190,11 +191,26 @@ int main(int argc, char **argv)
 			snprintf(buf, sizeof buf, "%s\"%d\": %.3f", wi ? ", " : "", w, wall);
 			js += buf;
 			if (wi == 3) { snprintf(buf, sizeof buf, ", \"ghz\": %.3f", g); js += buf; }
+			if (wi >= 1) {
+				all_ghz.push_back(g);
+				if (strncmp(en.name, "v_pk_", 5) == 0 || strcmp(en.name, "mix_pkadd_pkmax") == 0) half_rate_cost.push_back(wall);
+			}
 		}
 		js += "}";
 		printf("\n"); fflush(stdout);
 	}
-	js += "\n }\n}\n";
+	/* what bench.py prices SQ_INSTS_VALU with.  The step body of the sweep kernels is made of VOP3P packed 16-bit
+	 * operations, VOP3 bit-field operations and DPP moves: each occupies a SIMD for 4 cycles (64 lanes over 16 lanes per
+	 * cycle), and the 2-cycle VOP2 operations mixed in between cost 4 as well (the mix_* rows).  cycles_per_inst is that
+	 * architectural 4.0; measured_packed16_cost is what this run saw for the packed operations alone at 2-4 waves per SIMD
+	 * (loop overhead and clock ramp included); clock_ghz is the median clock the chip held under these loads. */
+	std::sort(all_ghz.begin(), all_ghz.end());
+	std::sort(half_rate_cost.begin(), half_rate_cost.end());
+	char rb[512];
+	snprintf(rb, sizeof rb, "\n },\n \"roofline\": {\"cycles_per_inst\": 4.0, \"clock_ghz\": %.3f, \"simds\": %d, "
+	         "\"measured_packed16_cost\": {\"min\": %.3f, \"median\": %.3f, \"max\": %.3f}}\n}\n",
+	         all_ghz[all_ghz.size() / 2], cus * 4, half_rate_cost.front(), half_rate_cost[half_rate_cost.size() / 2], half_rate_cost.back());
+	js += rb;
 	if (json_path) {
 		FILE *f = fopen(json_path, "w");
 		if (f) { fputs(js.c_str(), f); fclose(f); }

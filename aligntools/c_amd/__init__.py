@@ -41,6 +41,29 @@ class AlignToolsError(RuntimeError):
         self.code = code
 
 
+def _one_hip_runtime():
+    """One HIP runtime per process, whatever the import order.  PyTorch-ROCm bundles its own libamdhip64.so (same soname
+    as the system one the shim is linked against); a process that loads the system runtime first and torch's second ends up
+    with two, and torch then sees no GPU.  If torch is installed, its runtime is loaded here (by path, without importing
+    torch) before the shim: the shim's DT_NEEDED entry then resolves to it, and a later `import torch` finds it already
+    there.  Without torch (the C host, the CLI) the system runtime is used."""
+    import importlib.util
+    try:
+        spec = importlib.util.find_spec("torch")
+    except (ImportError, ValueError):
+        spec = None
+    if spec is None or not spec.submodule_search_locations:
+        return
+    for name in ("libamdhip64.so", "libamdhip64.so.7", "libamdhip64.so.6"):
+        cand = os.path.join(list(spec.submodule_search_locations)[0], "lib", name)
+        if os.path.exists(cand):
+            try:
+                C.CDLL(cand, mode=C.RTLD_GLOBAL)
+            except OSError:
+                pass
+            return
+
+
 def load_library():
     """Load the shim.  Raises if it has not been built (no silent fallback)."""
     global _lib
@@ -49,6 +72,7 @@ def load_library():
     if not os.path.exists(LIB_PATH):
         raise ImportError("aligntools.c_amd: %s is missing -- run `python -c 'import __graft_entry__ as g; g.build()'` "
                           "or `make -C aligntools/c_amd`; there is no CPU fallback" % LIB_PATH)
+    _one_hip_runtime()
     lib = C.CDLL(LIB_PATH)
     lib.at_init.restype = C.c_int
     lib.at_init.argtypes = [C.POINTER(C.c_int), C.c_int, C.POINTER(C.c_void_p)]

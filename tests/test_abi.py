@@ -78,3 +78,37 @@ def test_render_roundtrip_against_oracle(lib):
         r = O.align(O.MODE_NAMES[c["mode"]], c["s1"], c["s2"], c["m"], c["u"], c["o"], c["e"], c["j"], c["use_jump"], c["sites"])
         a, b = A.Aligner.render(al, r["ops"], c["s1"].encode("latin1"), r["end_i"], c["s2"].encode("latin1"), r["end_j"])
         assert (a, b) == (c["r1"], c["r2"])
+
+
+@pytest.mark.gpu
+def test_one_hip_runtime_whatever_the_import_order():
+    """The shim first, torch second (the order that used to leave torch without a GPU), and the other way round: both see
+    the device and one alignment comes out right (aligntools.c_amd._one_hip_runtime)."""
+    import subprocess
+    import sys
+    code = r'''
+import sys
+sys.path.insert(0, %r)
+first = sys.argv[1]
+if first == "shim":
+    import aligntools.c_amd as A
+    al = A.Aligner()
+    import torch
+else:
+    import torch
+    torch.cuda.is_available()
+    import aligntools.c_amd as A
+    al = A.Aligner()
+assert torch.cuda.is_available(), "torch lost the GPU"
+x = torch.arange(8, device="cuda").sum().item()
+al.set_scoring(2, -2, -5, -2, -10, False, [])
+r = al.align_batch("local", [("PLEASANTLY", "MEANLY")])
+assert x == 28 and int(r["score"][0]) == 4 and (r["r1"][0], r["r2"][0]) == ("LEA", "MEA")
+maps = open("/proc/self/maps").read()
+libs = sorted(set(l.split()[-1] for l in maps.splitlines() if "libamdhip64" in l))
+assert len(libs) == 1, libs
+print("ok", first, libs[0])
+''' % ROOT
+    for first in ("shim", "torch"):
+        p = subprocess.run([sys.executable, "-c", code, first], capture_output=True, text=True, timeout=600)
+        assert p.returncode == 0 and "ok " + first in p.stdout, p.stdout[-1500:] + p.stderr[-1500:]

@@ -298,17 +298,17 @@ struct Layout16 {
 /* Group width: reads of up to 152 bases run as 8 groups of 8 lanes x K rows (16 alignments per wave: 94 % of the
  * lane-steps inside a 150 x 150 matrix, the per-step overhead spread over 19 rows), up to 208 bases as 4 groups of 16
  * lanes (8 alignments per wave, 85 %; one group of 64 lanes: 59 %), 209..416 bases as 2 groups of 32 lanes, everything
- * else as one group of 64 lanes.  AT_GROUP = 16 / 64 caps the choice (A/B runs); ragged frames use the 16-lane kernels. */
-static Layout16 layout16_for(bool tb, bool hasj, int l1, int l2, int ts, bool force16 = false)
+ * else as one group of 64 lanes.  AT_GROUP = 16 / 64 caps the choice (A/B runs); ragged frames name their group width themselves. */
+static Layout16 layout16_for(bool tb, bool hasj, int l1, int l2, int ts, int force_g = 0)   /* force_g: 8 / 16 = ragged frames on that group width */
 {
 	Layout16 L;
 	const long long g_forced = env_ll("AT_GROUP", 0);
 	L.g = 64;
 	L.k = rows_per_lane(l1);
-	if (!force16 && (g_forced == 0 || g_forced == 8) && ts == 4 && l1 <= 152) {
+	if (force_g != 16 && (force_g == 8 || g_forced == 0 || g_forced == 8) && ts == 4 && l1 <= 152) {
 		L.g = 8;
 		L.k = l1 <= 40 ? 5 : l1 <= 56 ? 7 : l1 <= 80 ? 10 : l1 <= 104 ? 13 : l1 <= 128 ? 16 : 19;
-	} else if ((force16 || g_forced != 64) && ts == 4 && l1 <= 208) {
+	} else if ((force_g == 16 || g_forced != 64) && ts == 4 && l1 <= 208) {
 		L.g = 16;
 		L.k = l1 <= 64 ? 4 : l1 <= 80 ? 5 : l1 <= 96 ? 6 : l1 <= 112 ? 7 : (l1 <= 160 ? 10 : 13);
 	} else if (g_forced != 64 && ts == 4 && l1 > 208 && l1 <= 416) {
@@ -367,11 +367,11 @@ static bool packed_ok(const at_handle *h, int mode, int bits, int l1, int l2, in
 
 static int choose_store(long long words_fixed, long long words_ptr, bool prefer_hbm_pointers);
 /* is there a packed instantiation for the storage class plan_launch will choose for this layout? */
-static bool packed16_kernel_exists(int kmode, const Layout16 &P, bool tb, int ts, int bits, bool rag)
+static bool packed16_kernel_exists(int kmode, const Layout16 &P, bool tb, int ts, int bits, int rag)
 {
 	const int st = choose_store(P.off_ptr, P.words - P.off_ptr, P.g < 64);
 	if (P.g != 64 && st == 2) return false;
-	return (rag ? at_pick16_rag(P.k, st, tb, bits) : at_pick16(kmode, P.g, P.k, ts, st, tb, bits)) != nullptr;
+	return (rag ? at_pick16_rag(kmode, P.g, P.k, st, tb, bits) : at_pick16(kmode, P.g, P.k, ts, st, tb, bits)) != nullptr;
 }
 
 static int grow(at_handle *h, void **p, size_t *have, size_t need)
@@ -652,11 +652,11 @@ static int align_device(at_handle *h, int mode, int64_t npairs,
 		if (packed_ok(h, mode, bits, max_len1, max_len2, 4, &thresh16)) ts = 4;
 		else if (!rag && packed_ok(h, mode, bits, max_len1, max_len2, 2, &thresh16)) ts = 2;
 	}
-	if (rag && (!ts || kmode != at::K_LOCAL || max_len1 > 208 || !d_order))
+	if (rag && (!ts || kmode > at::K_FITJ || max_len1 > (rag == 8 ? 152 : 208) || !d_order))
 		return fail(h, AT_ERR_ARG, "ragged packed launch outside its domain");   /* the host entry checks before it asks */
 	Layout16 P;
 	if (ts) {
-		P = layout16_for(tb, kmode == at::K_FITJ, max_len1, max_len2, ts, rag != 0);
+		P = layout16_for(tb, kmode == at::K_FITJ, max_len1, max_len2, ts, rag);
 		/* A 64-lane packed wave carries 2 alignments where an int32 wave carries 1: fewer, longer work items.  A batch
 		 * that cannot give every resident wave one of them stays on the int32 kernel.  (10k x 1024^2 = 1.6 rounds: 1.96
 		 * packed vs 2.00 TCUPS int32 for a lone launch, 2.70 vs 2.13 with launches in flight; 61k pairs: 2.70 vs 2.19.) */
@@ -664,7 +664,7 @@ static int align_device(at_handle *h, int mode, int64_t npairs,
 		if (P.g == 64 && (double)((npairs + 1) / 2) < min_rounds * 12.0 * h->ncu) ts = 0;
 		/* no packed kernel for the storage class this shape needs (the 16- and 32-lane groups have no all-HBM variant:
 		 * a 150-base read against a second sequence of more than ~4 000 bases): the int32 kernel takes any length */
-		if (ts && !packed16_kernel_exists(kmode, P, tb, ts, bits, rag != 0)) {
+		if (ts && !packed16_kernel_exists(kmode, P, tb, ts, bits, rag)) {
 			if (rag) return fail(h, AT_ERR_ARG, "ragged packed launch outside its domain (frame too long for LDS)");
 			ts = 0;
 		}
@@ -693,7 +693,7 @@ static int align_device(at_handle *h, int mode, int64_t npairs,
 		char tag16[112];
 		snprintf(tag16, sizeof tag16, "packed16 x%d bits=%d %dx%d-lane groups (%d pairs/wave)%s", 1 << ts, bits, 64 / P.g, P.g, per_wave,
 		         rag ? " ragged frames" : "");
-		auto pick = [&](int st) { return rag ? at_pick16_rag(P.k, st, tb, bits) : at_pick16(kmode, P.g, P.k, ts, st, tb, bits); };
+		auto pick = [&](int st) { return rag ? at_pick16_rag(kmode, P.g, P.k, st, tb, bits) : at_pick16(kmode, P.g, P.k, ts, st, tb, bits); };
 		int rc = plan_launch(h, tag16, P.k, (npairs + per_wave - 1) / per_wave, P.off_ptr, P.words - P.off_ptr, &pl, stream,
 		                     [&](int st) { return (const void *)pick(st); }, P.g < 64);
 		if (rc) return rc;
@@ -912,9 +912,14 @@ static int align_host(at_handle *h, int mode, int64_t npairs, const uint8_t *seq
 	uint8_t *d_ops = (uint8_t *)(dout + 5 * b_len1);
 	int64_t *d_poff = (int64_t *)(dout + 5 * b_len1 + b_ops);   /* exclusive prefix sums of nops (tb only) */
 
-	/* ragged batch.  Local alignments of reads (l1 <= 208, 2-bit, scores within 16 bits) go to the packed kernel in
-	 * FRAMES: pairs are sorted by (rows-per-lane class of l1, l2), cut into buckets of similar size, and every bucket is
-	 * one launch whose work items sweep the bucket's largest extents while each alignment keeps its own (RAG kernels).
+	/* ragged batch.  Affine alignments of reads (l1 <= 208, scores within 16 bits) go to the packed kernels in FRAMES
+	 * (RAG kernels): a work item sweeps the extents its alignments need and every alignment keeps its own.
+	 *   local          pairs sorted by (rows-per-lane class of l1, l2), cut into buckets of similar l2, one launch per
+	 *                  bucket on the 16-lane groups; the alignments of an item may differ in l1 and l2
+	 *   global / fit   their end cells lie in row l1, so the alignments of an item share l1: pairs sorted by (l1, l2), every
+	 *                  run of equal l1 padded to whole work items by repeating its last pair (which is then computed twice,
+	 *                  same result to the same place), one launch per rows-per-lane class -- 8-lane groups up to 152 bases,
+	 *                  16-lane groups up to 208; an item sweeps the largest l2 among its own alignments
 	 * Everything else: the int32 kernel, pairs handed out largest first (the work queue is dynamic, so a big pair
 	 * picked up last would otherwise run alone at the end). */
 	int *d_order = nullptr;
@@ -923,30 +928,69 @@ static int align_host(at_handle *h, int mode, int64_t npairs, const uint8_t *seq
 	if (!uniform && npairs > 1 && npairs < (1LL << 31)) {
 		order.resize((size_t)npairs);
 		for (int64_t k = 0; k < npairs; ++k) order[(size_t)k] = (int)k;
-		int th = 0;
-		frames = mode == AT_MODE_LOCAL && max1 <= 208 && npairs >= 64 && env_ll("AT_RAGGED_PACKED", 1) &&
+		int th = 0, min1 = INT32_MAX, min2 = INT32_MAX;
+		for (int64_t k = 0; k < npairs; ++k) { min1 = std::min(min1, len1[k]); min2 = std::min(min2, len2[k]); }
+		const bool affine = mode == AT_MODE_LOCAL || mode == AT_MODE_GLOBAL || mode == AT_MODE_FIT;
+		const int kmode_f = mode == AT_MODE_LOCAL ? at::K_LOCAL : mode == AT_MODE_GLOBAL ? at::K_GLOBAL : h->use_jump ? at::K_FITJ : at::K_FIT;
+		frames = affine && max1 <= 208 && min1 >= 1 && min2 >= 1 && npairs >= 64 && env_ll("AT_RAGGED_PACKED", 1) &&
 		         packed_ok(h, mode, bits, max1, max2, 4, &th);
 		/* every frame is at most max1 x max2: if that one has no packed kernel (s2 too long for LDS), none is tried */
-		if (frames) frames = packed16_kernel_exists(at::K_LOCAL, layout16_for(tb, false, max1, max2, 4, true), tb, 4, bits, true);
-		auto kclass = [](int l1) { return l1 <= 64 ? 4 : l1 <= 80 ? 5 : l1 <= 96 ? 6 : l1 <= 112 ? 7 : l1 <= 160 ? 10 : 13; };
 		if (frames) {
+			const bool hasj = kmode_f == at::K_FITJ;
+			if (max1 > 152)
+				frames = packed16_kernel_exists(kmode_f, layout16_for(tb, hasj, max1, max2, 4, 16), tb, 4, bits, 16);
+			if (frames && (mode == AT_MODE_LOCAL ? max1 <= 152 : min1 <= 152))
+				frames = packed16_kernel_exists(kmode_f, layout16_for(tb, hasj, std::min(max1, 152), max2, 4, 8), tb, 4, bits, 8);
+		}
+		/* local: one group width for the whole batch (8 lanes while every read has at most 152 bases); rows per lane by read length */
+		const int gl = max1 <= 152 ? 8 : 16;
+		auto kclass = [gl](int l1) {
+			return gl == 8 ? (l1 <= 40 ? 5 : l1 <= 56 ? 7 : l1 <= 80 ? 10 : l1 <= 104 ? 13 : l1 <= 128 ? 16 : 19)
+			               : (l1 <= 64 ? 4 : l1 <= 80 ? 5 : l1 <= 96 ? 6 : l1 <= 112 ? 7 : l1 <= 160 ? 10 : 13);
+		};
+		/* global / fit: (group width, rows per lane) of a read length */
+		auto gclass = [](int l1) { return l1 <= 152 ? 8 : 16; };
+		auto kclass2 = [](int l1) { return l1 <= 40 ? 5 : l1 <= 56 ? 7 : l1 <= 80 ? 10 : l1 <= 104 ? 13 : l1 <= 128 ? 16 : l1 <= 152 ? 19 : l1 <= 160 ? 10 : 13; };
+		if (frames && mode == AT_MODE_LOCAL) {
 			/* (class descending, l2 descending, index ascending): a counting sort -- the key space is 6 x (max2 + 1) */
-			auto kidx = [&](int l1) { const int kc = kclass(l1); return kc == 13 ? 0 : kc == 10 ? 1 : kc == 7 ? 2 : kc == 6 ? 3 : kc == 5 ? 4 : 5; };
+			auto kidx = [&](int l1) {   /* classes in descending order of rows per lane */
+				const int kc = kclass(l1);
+				return gl == 8 ? (kc == 19 ? 0 : kc == 16 ? 1 : kc == 13 ? 2 : kc == 10 ? 3 : kc == 7 ? 4 : 5)
+				               : (kc == 13 ? 0 : kc == 10 ? 1 : kc == 7 ? 2 : kc == 6 ? 3 : kc == 5 ? 4 : 5);
+			};
 			const size_t span = (size_t)max2 + 1;
 			std::vector<int> start(6 * span + 1, 0);
 			for (int64_t k = 0; k < npairs; ++k) ++start[(size_t)kidx(len1[k]) * span + (size_t)(max2 - len2[k]) + 1];
 			for (size_t q = 1; q < start.size(); ++q) start[q] += start[q - 1];
 			for (int64_t k = 0; k < npairs; ++k) order[(size_t)start[(size_t)kidx(len1[k]) * span + (size_t)(max2 - len2[k])]++] = (int)k;
+		} else if (frames) {
+			/* (l1 descending, l2 descending, index ascending) by counting sort, then every run of equal l1 padded to whole
+			 * work items (16 alignments on the 8-lane groups, 8 on the 16-lane groups) */
+			const size_t span = (size_t)max2 + 1;
+			std::vector<int> start((size_t)(max1 + 1) * span + 1, 0);
+			for (int64_t k = 0; k < npairs; ++k) ++start[(size_t)(max1 - len1[k]) * span + (size_t)(max2 - len2[k]) + 1];
+			for (size_t q = 1; q < start.size(); ++q) start[q] += start[q - 1];
+			std::vector<int> sorted((size_t)npairs);
+			for (int64_t k = 0; k < npairs; ++k) sorted[(size_t)start[(size_t)(max1 - len1[k]) * span + (size_t)(max2 - len2[k])]++] = (int)k;
+			order.clear();
+			for (size_t b0 = 0; b0 < sorted.size();) {
+				size_t b1 = b0;
+				const size_t run0 = order.size();
+				while (b1 < sorted.size() && len1[sorted[b1]] == len1[sorted[b0]]) order.push_back(sorted[b1++]);
+				const size_t per = gclass(len1[sorted[b0]]) == 8 ? 16 : 8;
+				while ((order.size() - run0) % per) order.push_back(sorted[b1 - 1]);
+				b0 = b1;
+			}
 		} else
 			std::stable_sort(order.begin(), order.end(), [&](int x, int y) {
 				return (int64_t)len1[x] * len2[x] > (int64_t)len1[y] * len2[y];
 			});
-		rc = grow(h, &h->d_order, &h->order_bytes, (size_t)npairs * 4);
+		rc = grow(h, &h->d_order, &h->order_bytes, order.size() * 4);
 		if (rc) return rc;
 		d_order = (int *)h->d_order;
-		HIP_TRY(h, hipMemcpyAsync(d_order, order.data(), (size_t)npairs * 4, hipMemcpyHostToDevice, s));
+		HIP_TRY(h, hipMemcpyAsync(d_order, order.data(), order.size() * 4, hipMemcpyHostToDevice, s));
 		HIP_TRY(h, hipStreamSynchronize(s));
-		if (frames) {
+		if (frames && mode == AT_MODE_LOCAL) {
 			const int64_t min_bucket = env_ll("AT_RAGGED_MIN_BUCKET", 4096);
 			int nb = 0;
 			for (int64_t b0 = 0; b0 < npairs;) {
@@ -963,12 +1007,30 @@ static int align_host(at_handle *h, int mode, int64_t npairs, const uint8_t *seq
 				}
 				rc = align_device(h, mode, b1 - b0, d_words, bits, d_woff1, d_len1, d_woff2, d_len2, f1, l2first, 0, tb ? 1 : 0,
 				                  d_score, d_ei, d_ej, d_st, tb ? d_ops : nullptr, tb ? d_opsoff : nullptr, tb ? d_nops : nullptr, s,
-				                  0, 0, d_order + b0, 1);
+				                  0, 0, d_order + b0, gl);
 				if (rc) return rc;
 				b0 = b1;
 				++nb;
 			}
 			snprintf(h->cfg + strlen(h->cfg), sizeof h->cfg - strlen(h->cfg), " (%d frames)", nb);
+		} else if (frames) {
+			int nb = 0;
+			for (size_t b0 = 0; b0 < order.size();) {   /* one launch per (group width, rows per lane) */
+				const int g = gclass(len1[order[b0]]), kc = kclass2(len1[order[b0]]);
+				size_t b1 = b0;
+				int f1 = 0, f2 = 0;
+				while (b1 < order.size() && gclass(len1[order[b1]]) == g && kclass2(len1[order[b1]]) == kc) {
+					f1 = std::max(f1, len1[order[b1]]); f2 = std::max(f2, len2[order[b1]]);
+					++b1;
+				}
+				rc = align_device(h, mode, (int64_t)(b1 - b0), d_words, bits, d_woff1, d_len1, d_woff2, d_len2, f1, f2, 0, tb ? 1 : 0,
+				                  d_score, d_ei, d_ej, d_st, tb ? d_ops : nullptr, tb ? d_opsoff : nullptr, tb ? d_nops : nullptr, s,
+				                  0, 0, d_order + b0, g);
+				if (rc) return rc;
+				b0 = b1;
+				++nb;
+			}
+			snprintf(h->cfg + strlen(h->cfg), sizeof h->cfg - strlen(h->cfg), " (%d frames, equal-l1 work items)", nb);
 		}
 	}
 	if (!frames) {

@@ -5,7 +5,11 @@
 	at_sweep16_fn at_pick16_g16_b##b(int kmode, int k, int store, bool tb);        \
 	at_sweep16_fn at_pick16_g32_b##b(int kmode, int k, int store, bool tb);        \
 	at_sweep16_fn at_pick16_g8_b##b(int kmode, int k, int store, bool tb);         \
-	at_sweep16_fn at_pick16_rag_impl_b##b(int k, int store, bool tb);
+	at_sweep16_fn at_pick16_rag_impl_b##b(int k, int store, bool tb);                \
+	at_sweep16_fn at_pick16_rag8a_b##b(int kmode, int k, int store, bool tb);      \
+	at_sweep16_fn at_pick16_rag8b_b##b(int kmode, int k, int store, bool tb);      \
+	at_sweep16_fn at_pick16_rag8c_b##b(int kmode, int k, int store, bool tb);      \
+	at_sweep16_fn at_pick16_rag16_b##b(int kmode, int k, int store, bool tb);
 AT_DECL(2)
 AT_DECL(8)
 #undef AT_DECL
@@ -20,7 +24,13 @@ at_sweep16_fn at_pick16(int kmode, int g, int k, int ts, int store, bool tb, int
 	if (g == 16) return ts == 4 ? at_pick16_g16_b2(kmode, k, store, tb) : nullptr;
 	return ts == 4 ? at_pick16_g64_ts4_b2(kmode, k, store, tb) : at_pick16_g64_ts2_b2(kmode, k, store, tb);
 }
-at_sweep16_fn at_pick16_rag(int k, int store, bool tb, int bits)
+at_sweep16_fn at_pick16_rag(int kmode, int g, int k, int store, bool tb, int bits)
 {
-	return bits == 8 ? at_pick16_rag_impl_b8(k, store, tb) : at_pick16_rag_impl_b2(k, store, tb);
+	if (g == 8) {
+		if (bits == 8) return k >= 19 ? at_pick16_rag8c_b8(kmode, k, store, tb) : k >= 13 ? at_pick16_rag8b_b8(kmode, k, store, tb) : at_pick16_rag8a_b8(kmode, k, store, tb);
+		return k >= 19 ? at_pick16_rag8c_b2(kmode, k, store, tb) : k >= 13 ? at_pick16_rag8b_b2(kmode, k, store, tb) : at_pick16_rag8a_b2(kmode, k, store, tb);
+	}
+	if (g != 16) return nullptr;
+	if (kmode == at::K_LOCAL) return bits == 8 ? at_pick16_rag_impl_b8(k, store, tb) : at_pick16_rag_impl_b2(k, store, tb);
+	return bits == 8 ? at_pick16_rag16_b8(kmode, k, store, tb) : at_pick16_rag16_b2(kmode, k, store, tb);
 }

@@ -12,7 +12,7 @@ at_myers_fn at_pick_myers(int w, int g);   /* w in {1,2,4,8} 32-bit words per la
 /* store: 0 = everything in LDS, 1 = s2/boundary in LDS + pointers in the global slot, 2 = everything global */
 at_sweep_fn at_pick32_b2(int kmode, int k, int store, bool tb);
 at_sweep_fn at_pick32_b8(int kmode, int k, int store, bool tb);
-at_sweep16_fn at_pick16_rag(int k, int store, bool tb, int bits);   /* local, ragged frames: k in {4,5,6,7,10,13} */
+at_sweep16_fn at_pick16_rag(int kmode, int g, int k, int store, bool tb, int bits);   /* ragged frames: g in {8, 16} */
 at_sweep16_fn at_pick16(int kmode, int g, int k, int ts, int store, bool tb, int bits);
 /* every packed translation unit is compiled twice: -DAT_BITS16=2 (16 codes per sequence word, score LUT) and
  * -DAT_BITS16=8 (4 bytes per word, compare); its entry points carry the suffix _b2 / _b8 */

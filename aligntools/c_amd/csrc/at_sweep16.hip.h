@@ -66,7 +66,7 @@ struct Sweep16Args {
 	int off_refb, off_bound, off_ptr, off_sm, nsm;   /* off_sm/nsm: site mask words staged behind the boundary row */
 	int ptr_lanes;
 	unsigned long long *queue;     /* work counter, zeroed before every launch */
-	/* RAG kernels (local, ragged batch): l1 / l2 are the FRAME every work item is swept in, len1 / len2 the pairs' own
+	/* RAG kernels (ragged batch): l1 / l2 are the FRAME the launch is sized for, len1 / len2 the pairs' own
 	 * extents (<= the frame); work item w takes pairs order[2*NG*w ...] (pairs of similar size, chosen by the host) */
 	const int *order;
 	const int *only_if;            /* optional guard, see SweepArgs */
@@ -186,7 +186,7 @@ template <int MODE, int G, int K, int TS, bool SMALL, bool PTRLDS, bool TB, bool
 __global__ __launch_bounds__(64, AT_WAVES16(G, K)) void at_sweep16(const Sweep16Args a)
 {
 	static_assert(BITS == 2 || BITS == 8, "sequence words: 16 two-bit codes or 4 bytes");
-	static_assert(!RAG || (MODE == K_LOCAL && G == 16), "ragged frames: local, one strip");
+	static_assert(!RAG || G <= 16, "ragged frames: one strip");
 	static_assert(MODE == K_GLOBAL || MODE == K_LOCAL || MODE == K_FIT || MODE == K_FITJ, "packed path: the affine modes");
 	constexpr bool HASJ = MODE == K_FITJ;
 	constexpr bool ISFIT = MODE == K_FIT || MODE == K_FITJ;
@@ -237,10 +237,8 @@ __global__ __launch_bounds__(64, AT_WAVES16(G, K)) void at_sweep16(const Sweep16
 	asm volatile("" : "+v"(o2), "+v"(e2), "+v"(lut_lo), "+v"(lut_hi));
 	asm volatile("" : "+v"(cClean), "+v"(cTagM), "+v"(cTagL), "+v"(cTagU), "+v"(cM3), "+v"(cM7), "+v"(cNib), "+v"(cF0), "+v"(cF000));
 	const int nstrips = (l1 + RS - 1) / RS;   /* host guarantees 1 when G < 64 */
-	const int tbk = (l2 + G - 1 + BLK - 1) / BLK;
-	const int wps = tbk * RPB * K;            /* pointer word rows per strip */
-	const int lastlane = l1 > 0 ? ((l1 - 1) % RS) / K : 0;   /* lane-in-group owning row l1 */
-	const int rl = l1 > 0 ? ((l1 - 1) % RS) % K : 0;
+	const int tbk_frame = (l2 + G - 1 + BLK - 1) / BLK;
+	const int wps = tbk_frame * RPB * K;      /* pointer word rows per strip (the layout of the slot: always the frame's) */
 	const long long nwork = (a.npairs + 2 * NG - 1) / (2 * NG);
 	const int refoff = grp * 2 * a.off_refb;  /* my group's two s2 byte arrays */
 
@@ -254,6 +252,11 @@ __global__ __launch_bounds__(64, AT_WAVES16(G, K)) void at_sweep16(const Sweep16
 		long long pA = (wk * NG + grp) * 2 < a.npairs ? (wk * NG + grp) * 2 : last;
 		long long pB = (wk * NG + grp) * 2 + 1 < a.npairs ? (wk * NG + grp) * 2 + 1 : last;
 		int l1A = l1, l1B = l1, l2A = l2, l2B = l2;   /* the alignments' own extents (RAG: inside the frame l1 x l2) */
+		/* the extents this work item is swept in.  Uniform batches: the batch's shape.  RAG: il2 = the largest l2 of the
+		 * item's alignments (columns behind an alignment's own l2 feed nothing inside it); il1 = the frame's l1 for local
+		 * (rows behind an alignment's own l1 are masked out of its arg-max), and for global / fit, whose end cells lie in
+		 * row l1, the COMMON l1 of the item's alignments -- the host puts reads of equal length together. */
+		int il1 = l1, il2 = l2;
 		long long pout = 0;                            /* lanes 0 .. 2*NG-1: where the results of alignment `lane` go */
 		if constexpr (RAG) {
 			const long long pc = wk * 2 * NG + lane < a.npairs ? wk * 2 * NG + lane : last;
@@ -262,8 +265,13 @@ __global__ __launch_bounds__(64, AT_WAVES16(G, K)) void at_sweep16(const Sweep16
 			pA = __shfl((int)pout, 2 * grp); pB = __shfl((int)pout, 2 * grp + 1);
 			l1A = __shfl(o1, 2 * grp); l1B = __shfl(o1, 2 * grp + 1);
 			l2A = __shfl(o2l, 2 * grp); l2B = __shfl(o2l, 2 * grp + 1);
-			const bool bad = lane < 2 * NG && (o1 > l1 || o2l > l2 || o1 < 1 || o2l < 1);
-			if (__any(bad)) {   /* a pair that does not fit the frame (or is empty: outside local's domain) */
+			int mx = o2l;
+#pragma unroll
+			for (int d = 1; d < 2 * NG; d <<= 1) mx = imax(mx, __shfl_xor(mx, d));
+			il2 = __builtin_amdgcn_readfirstlane(mx);
+			if constexpr (MODE != K_LOCAL) il1 = __builtin_amdgcn_readfirstlane(o1);
+			const bool bad = lane < 2 * NG && (o1 > l1 || o2l > l2 || o1 < 1 || o2l < 1 || (MODE != K_LOCAL && o1 != il1));
+			if (__any(bad)) {   /* a pair that does not fit the frame, is empty, or (global / fit) breaks the item's common l1 */
 				if (lane < 2 * NG && wk * 2 * NG + lane < a.npairs) {
 					a.score[pout] = INT32_MIN;
 					if (a.nops) a.nops[pout] = -1;
@@ -284,13 +292,16 @@ __global__ __launch_bounds__(64, AT_WAVES16(G, K)) void at_sweep16(const Sweep16
 				continue;
 			}
 		}
+		const int tbk = RAG ? (il2 + G - 1 + BLK - 1) / BLK : tbk_frame;
+		const int lastlane = il1 > 0 ? ((il1 - 1) % RS) / K : 0;   /* lane-in-group owning row l1 */
+		const int rl = il1 > 0 ? ((il1 - 1) % RS) % K : 0;
 		const uint32_t *qA = a.seq + a.woff1[pA], *qB = a.seq + a.woff1[pB];
 		const uint32_t *rA = a.seq + a.woff2[pA], *rB = a.seq + a.woff2[pB];
 
 		/* ---- stage both s2 of my group as bytes (coalesced int32 reads of the 2-bit words) ---- */
 		{
 			constexpr int BPW = 32 / BITS;         /* bases per sequence word */
-			const int nw2 = (l2 + BPW - 1) / BPW;
+			const int nw2 = (il2 + BPW - 1) / BPW;
 			const int nwA = (l2A + BPW - 1) / BPW, nwB = (l2B + BPW - 1) / BPW;   /* RAG: never read behind an alignment's own words */
 			for (int w = lg; w < nw2; w += G) {
 				const uint32_t va = rA[RAG ? imin(w, nwA - 1) : w], vb = rB[RAG ? imin(w, nwB - 1) : w];
@@ -323,6 +334,7 @@ __global__ __launch_bounds__(64, AT_WAVES16(G, K)) void at_sweep16(const Sweep16
 		/* running results, per half */
 		int gbi[2] = {INT32_MAX, INT32_MAX}, gbj[2] = {INT32_MAX, INT32_MAX}, gbs[2] = {INT32_MIN, INT32_MIN};
 		uint32_t bestM = pk2(a.thresh16), bestMj = 0, bestL = pk2(a.thresh16), bestLj = 0;   /* fit scans */
+		uint32_t capL = 0, capM = 0, capU = 0;         /* RAG global: the three states of each alignment's own cell (l1, l2) */
 		/* Xl: X' of my rows at the previous column (the diagonal input of the row below).  Two copies used in turn
 		 * (step parity), so that the old value can be read while the new one is written without register moves. */
 		uint32_t Mo_l[K], U_l[K], Xl[2][K], L_l[K], J_l[K];
@@ -330,7 +342,7 @@ __global__ __launch_bounds__(64, AT_WAVES16(G, K)) void at_sweep16(const Sweep16
 		for (int s = 0; s < nstrips; ++s) {
 			const int base = s * RS;
 			const int i0 = base + lg * K;
-			const int nl = imin(G, (l1 - base + K - 1) / K);
+			const int nl = imin(G, (il1 - base + K - 1) / K);
 			const bool laststrip = s == nstrips - 1;
 			const bool wb = G == 64 && !laststrip;
 			uint32_t qsel[K], acc[K], keymask[K];
@@ -417,7 +429,7 @@ __global__ __launch_bounds__(64, AT_WAVES16(G, K)) void at_sweep16(const Sweep16
 					const uint32_t Bup = grp_up1<G>((uint32_t)row_shl<k>((int)bl), B_prev);
 					const int jm1 = jm1_0 + k;
 					bool active = true;
-					if constexpr (masked) active = lg < nl && (unsigned)jm1 < (unsigned)l2;
+					if constexpr (masked) active = lg < nl && (unsigned)jm1 < (unsigned)il2;
 					if (active) {
 						uint32_t gopen = neg2;
 						if constexpr (HASJ) gopen = ((sm >> k) & 1u) ? gmo2 : neg2;
@@ -426,11 +438,16 @@ __global__ __launch_bounds__(64, AT_WAVES16(G, K)) void at_sweep16(const Sweep16
 							 * every lane scans its own row rl, only the owner of row l1 is read at the end */
 							if (laststrip) {
 								const uint32_t jpk = pk2(jm1);
-								const uint32_t vM = psub(pick<K>(Mo_l, rl), o2);
+								uint32_t vM = psub(pick<K>(Mo_l, rl), o2);
+								uint32_t vL = pick<K>(L_l, rl);
+								if constexpr (RAG) {
+									/* an alignment's scan ends at its own column l2 - 1 */
+									const uint32_t cm = (((uint32_t)((jm1 - l2A) >> 31)) & 0xffffu) | (((uint32_t)((jm1 - l2B) >> 31)) << 16);
+									vM = vbfi(cm, vM, neg2); vL = vbfi(cm, vL, neg2);
+								}
 								uint32_t dM = psub(bestM, vM);
 								asm("" : "+v"(dM));
 								bestMj = vbfi(pneg(dM), jpk, bestMj); bestM = pmax(bestM, vM);
-								const uint32_t vL = pick<K>(L_l, rl);
 								uint32_t dL = psub(bestL, vL);
 								asm("" : "+v"(dL));
 								bestLj = vbfi(pneg(dL), jpk, bestLj); bestL = pmax(bestL, vL);
@@ -439,6 +456,12 @@ __global__ __launch_bounds__(64, AT_WAVES16(G, K)) void at_sweep16(const Sweep16
 						/* step k's byte of each window against each of my query bases */
 						const uint32_t selw = __builtin_amdgcn_perm(wB[hw], wA[hw], SELK);   /* [b, b, a, a] */
 						uint32_t diag = Ad, lraw = Bup, up = 0, cmax[NCH];
+						uint32_t capmask = 0;
+						if constexpr (RAG && MODE == K_GLOBAL) {
+							/* the sweep passes each alignment's end cell (l1, l2 of its own) on its way through the frame: the
+							 * lane that owns row l1 keeps the cell's three states when its column comes by */
+							if (lg == lastlane) capmask = (jm1 + 1 == l2A ? 0xffffu : 0u) | (jm1 + 1 == l2B ? 0xffff0000u : 0u);
+						}
 #pragma unroll
 						for (int r = 0; r < K; ++r) {
 							/* x = s2 byte ^ query byte (0 = match): selector {xB+4, xB, xA+4, xA} -> the two 16-bit scores */
@@ -466,6 +489,9 @@ __global__ __launch_bounds__(64, AT_WAVES16(G, K)) void at_sweep16(const Sweep16
 								J_l[r] = Jc;
 							}
 							const uint32_t Ld = pmax(padd(Lc, e2), Mo);
+							if constexpr (RAG && MODE == K_GLOBAL) {
+								if (r == rl) { capL = vbfi(capmask, Lc, capL); capM = vbfi(capmask, Mc, capM); capU = vbfi(capmask, Uc, capU); }
+							}
 							if constexpr (TB) {
 								/* the cell's pointer bits, in the low bits of each 16-bit half (what lies above them is junk
 								 * until the word is assembled): [1:0] pM, bit 2: L extended, bit 3: the U winner's tag bit, bit 4: J opened */
@@ -556,7 +582,7 @@ __global__ __launch_bounds__(64, AT_WAVES16(G, K)) void at_sweep16(const Sweep16
 		step(std::integral_constant<int, 6>{}, M{}); step(std::integral_constant<int, 7>{}, M{});        \
 	}
 				if constexpr (ONEBODY) { AT_STEPS16(T) }
-				else if (t0 >= nl - 1 && t0 + BLK <= l2) { AT_STEPS16(F) }
+				else if (t0 >= nl - 1 && t0 + BLK <= il2) { AT_STEPS16(F) }
 				else { AT_STEPS16(T) }
 #undef AT_STEPS16
 				bx = bxn; bl = bln;
@@ -602,18 +628,27 @@ __global__ __launch_bounds__(64, AT_WAVES16(G, K)) void at_sweep16(const Sweep16
 				cj = __builtin_amdgcn_readlane(bj, glane); st = 2;
 			} else if constexpr (MODE == K_GLOBAL) {
 				const int own = glane + lastlane;
-				const int eL = half((uint32_t)__builtin_amdgcn_readlane((int)pick<K>(L_l, rl), own), h);
-				const int eM = half(psub((uint32_t)__builtin_amdgcn_readlane((int)pick<K>(Mo_l, rl), own), pk2(o16)), h);
-				const int eU = half((uint32_t)__builtin_amdgcn_readlane((int)pick<K>(U_l, rl), own), h);
+				int eL, eM, eU;
+				if constexpr (RAG) {
+					eL = half((uint32_t)__builtin_amdgcn_readlane((int)capL, own), h);
+					eM = half((uint32_t)__builtin_amdgcn_readlane((int)capM, own), h);
+					eU = half((uint32_t)__builtin_amdgcn_readlane((int)capU, own), h);
+					cj = __builtin_amdgcn_readlane(h ? l2B : l2A, glane);
+				} else {
+					eL = half((uint32_t)__builtin_amdgcn_readlane((int)pick<K>(L_l, rl), own), h);
+					eM = half(psub((uint32_t)__builtin_amdgcn_readlane((int)pick<K>(Mo_l, rl), own), pk2(o16)), h);
+					eU = half((uint32_t)__builtin_amdgcn_readlane((int)pick<K>(U_l, rl), own), h);
+					cj = l2;
+				}
 				const int x = TB ? imax3(eL, eM, eU) : imax3(eL | OTGL, eM | OTGM, eU | OTGU);   /* max5(L,M,U) first-wins :466 */
-				sc16 = x; st = x & 3; ci = l1; cj = l2;
+				sc16 = x; st = x & 3; ci = il1;
 			} else {
 				const int own = glane + lastlane;
 				const int bM = half((uint32_t)__builtin_amdgcn_readlane((int)bestM, own), h);
 				const int jM = half((uint32_t)__builtin_amdgcn_readlane((int)bestMj, own), h);
 				const int bL = half((uint32_t)__builtin_amdgcn_readlane((int)bestL, own), h);
 				const int jL = half((uint32_t)__builtin_amdgcn_readlane((int)bestLj, own), h);
-				ci = l1;
+				ci = il1;
 				if ((bL >> TS) > (bM >> TS) && bL > a.thresh16) { sc16 = bL; st = 3; cj = jL; }
 				else { sc16 = bM; st = 2; cj = jM; }
 				ok = sc16 > a.thresh16;

@@ -518,6 +518,58 @@ def test_ragged_local_batches_in_frames(al):
     assert int(res["score"][-1]) == r["score"] and res["ops"][-1] == r["ops"]
 
 
+@pytest.mark.parametrize("mode", ["global", "fit", "fitj"])
+def test_ragged_global_and_fit_batches_in_frames(al, mode):
+    """Ragged global / fit / fit -s batches of reads (l1 <= 208) run on the packed kernels in frames whose work items hold
+    reads of one length: 8-lane groups up to 152 bases, 16-lane groups beyond; l2 differs inside an item.  Length mixes
+    around every rows-per-lane class edge, a few lengths that occur once (their items are padded with repeats), related and
+    unrelated pairs, both alphabets, with and without tracebacks -- score / end cell / start state / ops against the
+    oracle; a batch with one read of 209 bases falls back to the int32 kernel."""
+    rng = random.Random(4471)
+    uj = mode == "fitj"
+    m = "fit" if uj else mode
+    for alpha, lens in (("ACGT", [1, 2, 39, 40, 41, 56, 57, 80, 81, 104, 105, 128, 129, 150, 151, 152, 153, 160, 161, 200, 208]), ("ACGTN", [30, 100, 150, 180])):
+        dna = lambda n: "".join(rng.choice(alpha) for _ in range(n))
+        pairs = []
+        for k in range(1400):
+            l1 = rng.choice(lens) if k % 4 else rng.randint(1, 208)
+            l2 = rng.randint(max(l1, 2), max(l1, 2) + rng.choice([0, 5, 60, 300]))
+            a = dna(l1)
+            if k % 2:
+                t = list(a)
+                for _ in range(max(1, l1 // 15)):
+                    q = rng.randrange(len(t))
+                    r = rng.random()
+                    if r < 0.4:
+                        t[q] = rng.choice(alpha)
+                    elif r < 0.7 and len(t) > 1:
+                        del t[q]
+                    else:
+                        t.insert(q, rng.choice(alpha))
+                b = (dna(rng.randint(0, 30)) + "".join(t) + dna(l2))[:l2]
+            else:
+                b = dna(l2)
+            pairs.append((a, b))
+        sites = [20, 100, 250, 400]
+        for sc in ((2, -2, -5, -1, -10), (1, -1, -1, -1, -3)):
+            al.set_scoring(*sc, uj, sites)
+            for tb in (True, False):
+                res = al.align_batch(m, pairs, traceback=tb, render=False)
+                assert "equal-l1 work items" in al.last_config, al.last_config
+                for k, (a, b) in enumerate(pairs):
+                    r = O.align(O.MODE_NAMES[m], a, b, *sc, uj, sites)
+                    assert (int(res["score"][k]), int(res["end_i"][k]), int(res["end_j"][k]), int(res["state"][k])) == \
+                           (r["score"], r["end_i"], r["end_j"], r["state"]), (mode, alpha, sc, tb, k, len(a), len(b))
+                    if tb:
+                        assert res["ops"][k] == r["ops"], (mode, alpha, sc, k, len(a), len(b))
+    al.set_scoring(2, -2, -5, -1, -10, uj, sites)
+    longer = pairs[:200] + [(dna(209), dna(400))]
+    res = al.align_batch(m, longer, render=False)
+    assert "int32" in al.last_config
+    r = O.align(O.MODE_NAMES[m], longer[-1][0], longer[-1][1], 2, -2, -5, -1, -10, uj, sites)
+    assert int(res["score"][-1]) == r["score"] and res["ops"][-1] == r["ops"]
+
+
 def test_chunked_host_entry(al):
     """Batches of >= 32k pairs go through the host entry as chunks on helper handles and threads: the results equal
     the one-piece run (AT_HOST_CHUNKS=1), ragged shapes included, and an error names the pair by its batch index."""

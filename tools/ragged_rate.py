@@ -1,5 +1,10 @@
-"""Host-entry rate on a RAGGED batch (every pair its own lengths -> int32 kernel, largest pairs first), against the same
-number of cells in uniform 150 x 150 pairs (packed kernel).  100k pairs, local, tracebacks."""
+"""Host-entry rate (at_align_batch: upload, GPU packing, sweep, download) on RAGGED batches -- every pair its own lengths,
+packed kernels in frames -- against uniform batches of the workload's nominal shape.  100k pairs, tracebacks.
+
+    local   150 x 150        vs   100..150 x 100..150 and 30..150 x 30..150
+    fit -s  150 x 500 (C4)   vs   100..150 x 400..500
+    global  150 x 150        vs   100..150 x 100..150
+"""
 import ctypes as C
 import os
 import sys
@@ -14,24 +19,34 @@ from aligntools.c_amd.synth import synth_pairs_blob
 n = 100000
 rng = np.random.default_rng(5)
 al = A.Aligner(0)
-al.set_scoring(2, -2, -5, -2)
 lib = A.load_library()
 p = lambda a: a.ctypes.data_as(C.c_void_p)
-for name, lo in (("uniform 150x150", 150), ("ragged 100..150 x 100..150", 100), ("ragged 30..150 x 30..150", 30)):
-    len1 = rng.integers(lo, 151, n).astype(np.int32)
-    len2 = rng.integers(lo, 151, n).astype(np.int32)
-    blob = synth_pairs_blob(0x5EED0002, n, 150, 150).reshape(-1).copy()
-    off1 = np.arange(n, dtype=np.int64) * 300
-    off2 = off1 + 150
-    score, ei, ej, st, nops = (np.zeros(n, np.int32) for _ in range(5))
-    ops = np.zeros(n * 300 + 64, np.uint8)
-    ts = []
-    for it in range(5):
-        t0 = time.perf_counter()
-        rc = lib.at_align_batch(al._h, A.MODE_LOCAL, n, p(blob), p(off1), p(len1), p(off2), p(len2), 1, p(score), p(ei), p(ej), p(st),
-                                p(ops), p(off1), p(nops))
-        ts.append(time.perf_counter() - t0)
-        assert rc == 0
-    t = min(ts[1:])
-    cells = float((len1.astype(np.int64) * len2).sum())
-    print("%-28s %.2f ms = %.0f GCUPS host path (%s)" % (name, t * 1e3, cells / t / 1e9, al.last_config[:60]))
+CASES = [
+    ("local", (2, -2, -5, -2, -10), False, [], 150, 150, [("uniform 150x150", 150, 150), ("ragged 100..150 x 100..150", 100, 100), ("ragged 30..150 x 30..150", 30, 30)]),
+    ("fit", (2, -2, -5, -1, -10), True, [100, 200, 300, 400], 150, 500, [("uniform 150x500 (C4)", 150, 500), ("ragged 100..150 x 400..500", 100, 400)]),
+    ("global", (1, -1, -4, -1, -10), False, [], 150, 150, [("uniform 150x150", 150, 150), ("ragged 100..150 x 100..150", 100, 100)]),
+]
+for mode, sc, uj, sites, L1, L2, rows in CASES:
+    al.set_scoring(*sc, uj, sites)
+    blob = synth_pairs_blob(0x5EED0002, n, L1, L2).reshape(-1).copy()
+    off1 = np.arange(n, dtype=np.int64) * (L1 + L2)
+    off2 = off1 + L1
+    base = None
+    for name, lo1, lo2 in rows:
+        len1 = rng.integers(lo1, L1 + 1, n).astype(np.int32)
+        len2 = rng.integers(lo2, L2 + 1, n).astype(np.int32)
+        score, ei, ej, st, nops = (np.zeros(n, np.int32) for _ in range(5))
+        ops = np.zeros(n * (L1 + L2) + 64, np.uint8)
+        ts = []
+        for it in range(5):
+            t0 = time.perf_counter()
+            rc = lib.at_align_batch(al._h, A.MODES[mode], n, p(blob), p(off1), p(len1), p(off2), p(len2), 1, p(score), p(ei), p(ej), p(st),
+                                    p(ops), p(off1), p(nops))
+            ts.append(time.perf_counter() - t0)
+            assert rc == 0, lib.at_last_error(al._h)
+        t = min(ts[1:])
+        cells = float((len1.astype(np.int64) * len2).sum())
+        rate = cells / t / 1e9
+        base = base or rate
+        print("%-7s %-28s %7.2f ms = %5.0f GCUPS host path, %3.0f %% of uniform (%s)" % (mode + (" -s" if uj else ""), name, t * 1e3, rate, 100 * rate / base,
+                                                                                   al.last_config[:90]), flush=True)

@@ -25,7 +25,8 @@ ST_LOW, ST_MID, ST_UPP = 1, 2, 3
 # every symbol include/aligntools_hip.h declares
 ABI_SYMBOLS = ["at_init", "at_destroy", "at_last_error", "at_set_scoring", "at_align_batch",
                "at_align_batch_device", "at_align_allpairs_device", "at_render_batch_device", "at_compact_ops_device",
-               "at_align_batch_strings",
+               "at_align_batch_strings", "at_align_allpairs",
+               "at_comm_init", "at_comm_broadcast_scoring", "at_comm_allgather", "at_comm_destroy",
                "at_pack_words", "at_pack_batch", "at_render", "at_last_config"]
 
 _i32p = C.POINTER(C.c_int32)
@@ -104,6 +105,9 @@ def load_library():
                                           C.c_void_p, C.c_void_p]
     lib.at_align_batch_strings.restype = C.c_int
     lib.at_align_batch_strings.argtypes = [C.c_void_p, C.c_int, C.c_int64] + [C.c_void_p] * 13
+    lib.at_align_allpairs.restype = C.c_int
+    lib.at_align_allpairs.argtypes = [C.c_void_p, C.c_int, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_int,
+                                      C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
     lib.at_pack_words.restype = C.c_int64
     lib.at_pack_words.argtypes = [C.c_int64, C.c_void_p, C.c_void_p, C.c_int]
     lib.at_pack_batch.restype = C.c_int

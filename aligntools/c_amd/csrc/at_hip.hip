@@ -43,6 +43,7 @@ struct at_handle {
 	void *d_scan = nullptr; size_t scan_bytes = 0;
 	int *d_rflag = nullptr;         /* at_render_k's "op list walks off its sequences" flag */
 	std::vector<at_handle *> kids;  /* helper handles of the host entry: chunks of one batch in flight side by side */
+	void *comm = nullptr;           /* multi-process batches: the communicator (at_comm.hip) */
 	char err[512] = {0};
 	char cfg[320] = "none";
 };
@@ -107,9 +108,21 @@ extern "C" int at_init(const int *device_ids, int n_devices, at_handle **out)
 	return AT_OK;
 }
 
+extern "C" void at_comm_destroy(at_handle *h);
+/* what at_comm.hip needs of a handle */
+extern "C" int at_handle_device(const at_handle *h) { return h->device; }
+extern "C" int at_comm_fail(at_handle *h, int code, const char *msg) { return fail(h, code, "%s", msg); }
+extern "C" void **at_comm_slot(at_handle *h) { return &h->comm; }
+extern "C" void at_get_scoring(const at_handle *h, int *v7, const int **sites)
+{
+	v7[0] = h->m; v7[1] = h->u; v7[2] = h->o; v7[3] = h->e; v7[4] = h->j; v7[5] = h->use_jump; v7[6] = (int)h->sites.size();
+	*sites = h->sites.data();
+}
+
 extern "C" void at_destroy(at_handle *h)
 {
 	if (!h) return;
+	if (h->comm) at_comm_destroy(h);
 	for (at_handle *k : h->kids) at_destroy(k);
 	h->kids.clear();
 	(void)hipSetDevice(h->device);
@@ -1157,6 +1170,125 @@ static int align_host_mt(at_handle *h, int mode, int64_t npairs, const uint8_t *
 		}
 	}
 	snprintf(h->cfg + strlen(h->cfg), sizeof h->cfg - strlen(h->cfg), " x%d chunks", nchunks);
+	return AT_OK;
+}
+
+/* all-vs-all over one read set held in HOST memory: the reads go up once, are packed once, and pairs
+ * [first_pair, first_pair + npairs) of the strict upper triangle are enumerated on the GPU (at_align_allpairs_device) */
+extern "C" int at_align_allpairs(at_handle *h, int mode, int64_t nreads, const uint8_t *seq_blob,
+                                 const int64_t *off, const int32_t *len, int64_t first_pair, int64_t npairs, int want_traceback,
+                                 int32_t *out_score, int32_t *out_end_i, int32_t *out_end_j, int32_t *out_state,
+                                 uint8_t *out_ops, const int64_t *ops_off, int32_t *out_nops)
+{
+	if (!h) return fail(nullptr, AT_ERR_ARG, "at_align_allpairs: NULL handle");
+	if (mode < AT_MODE_GLOBAL || mode > AT_MODE_EDIT) return fail(h, AT_ERR_ARG, "unknown mode %d", mode);
+	if (nreads < 2 || first_pair < 0 || npairs < 0 || first_pair + npairs > nreads * (nreads - 1) / 2)
+		return fail(h, AT_ERR_ARG, "all-vs-all: pair range [%lld, +%lld) outside the %lld*(%lld-1)/2 ordered pairs",
+		            (long long)first_pair, (long long)npairs, (long long)nreads, (long long)nreads);
+	if (npairs == 0) return AT_OK;
+	if (!seq_blob || !off || !len || !out_score) return fail(h, AT_ERR_ARG, "NULL argument");
+	const bool tb = want_traceback && mode != AT_MODE_EDIT;
+	if (tb && (!out_ops || !ops_off || !out_nops)) return fail(h, AT_ERR_ARG, "traceback wanted but ops buffers are NULL");
+	int maxlen = 0;
+	int64_t blob_lo = INT64_MAX, blob_bytes = 0, nwords2 = 0, nwords8 = 0;
+	std::vector<int64_t> soff((size_t)nreads), swoff2((size_t)nreads), swoff8((size_t)nreads);
+	for (int64_t k = 0; k < nreads; ++k) {
+		if (len[k] < 0 || off[k] < 0) return fail(h, AT_ERR_ARG, "read %lld: negative length or offset", (long long)k);
+		if ((mode == AT_MODE_LOCAL || mode == AT_MODE_OVERLAP) && len[k] < 1) return fail(h, AT_ERR_DOMAIN, "read %lld: empty", (long long)k);
+		if (mode == AT_MODE_FIT) return fail(h, AT_ERR_ARG, "all-vs-all: fit needs ordered lengths (l1 <= l2); use the pair list entry");
+		maxlen = std::max(maxlen, len[k]);
+		blob_lo = std::min(blob_lo, off[k]);
+	}
+	for (int64_t k = 0; k < nreads; ++k) {
+		soff[(size_t)k] = off[k] - blob_lo;
+		swoff2[(size_t)k] = nwords2; nwords2 += (len[k] + 15) / 16 + 1;
+		swoff8[(size_t)k] = nwords8; nwords8 += (len[k] + 3) / 4 + 1;
+		blob_bytes = std::max<int64_t>(blob_bytes, soff[(size_t)k] + len[k]);
+	}
+	int64_t ops_total = 0, ops_lo = 0, slots_total = 0;
+	std::vector<int64_t> opsr;
+	if (tb) {
+		ops_lo = INT64_MAX;
+		for (int64_t p = 0; p < npairs; ++p) { if (ops_off[p] < 0) return fail(h, AT_ERR_ARG, "pair %lld: negative ops offset", (long long)p); ops_lo = std::min(ops_lo, ops_off[p]); }
+		opsr.resize((size_t)npairs);
+		for (int64_t p = 0; p < npairs; ++p) { opsr[(size_t)p] = ops_off[p] - ops_lo; ops_total = std::max<int64_t>(ops_total, opsr[(size_t)p] + 2LL * maxlen); }
+		slots_total = npairs * 2LL * maxlen;
+	}
+	HIP_TRY(h, hipSetDevice(h->device));
+	auto al = [](size_t x) { return (x + 255) & ~(size_t)255; };
+	const size_t b_words = al((size_t)(std::max(nwords2, nwords8) + 4) * 4), b_off = al((size_t)nreads * 8), b_len = al((size_t)nreads * 4);
+	const size_t b_opsoff = al((size_t)npairs * 8), b_blob = al((size_t)blob_bytes + 16);
+	int rc = grow(h, &h->d_in, &h->in_bytes, b_words + 2 * b_off + b_len + 256 + b_opsoff + b_blob);
+	if (rc) return rc;
+	char *din = (char *)h->d_in;
+	uint32_t *d_words = (uint32_t *)din;
+	int64_t *d_soff = (int64_t *)(din + b_words), *d_swoff = (int64_t *)(din + b_words + b_off);
+	int32_t *d_len = (int32_t *)(din + b_words + 2 * b_off);
+	int *d_flag = (int *)(din + b_words + 2 * b_off + b_len);
+	int64_t *d_opsoff = (int64_t *)(din + b_words + 2 * b_off + b_len + 256);
+	uint8_t *d_blob = (uint8_t *)(din + b_words + 2 * b_off + b_len + 256 + b_opsoff);
+	hipStream_t s = h->stream;
+	HIP_TRY(h, hipMemcpyAsync(d_blob, seq_blob + blob_lo, (size_t)blob_bytes, hipMemcpyHostToDevice, s));
+	HIP_TRY(h, hipMemcpyAsync(d_soff, soff.data(), (size_t)nreads * 8, hipMemcpyHostToDevice, s));
+	HIP_TRY(h, hipMemcpyAsync(d_len, len, (size_t)nreads * 4, hipMemcpyHostToDevice, s));
+	if (tb) HIP_TRY(h, hipMemcpyAsync(d_opsoff, opsr.data(), (size_t)npairs * 8, hipMemcpyHostToDevice, s));
+	at::PackArgs pa;
+	pa.nseq = nreads; pa.blob = d_blob; pa.off = (const long long *)d_soff; pa.len = d_len;
+	pa.woff = (const long long *)d_swoff; pa.words = d_words; pa.not_acgt = d_flag;
+	const unsigned pgrid = (unsigned)std::min<int64_t>((nreads + 3) / 4, 8LL * h->ncu);
+	int bits = scores_fit_byte(h, mode) ? 2 : 8, flag = 0;
+	if (bits == 2) {
+		HIP_TRY(h, hipMemsetAsync(d_flag, 0, 4, s));
+		HIP_TRY(h, hipMemcpyAsync(d_swoff, swoff2.data(), (size_t)nreads * 8, hipMemcpyHostToDevice, s));
+		hipLaunchKernelGGL(at::at_pack<2>, dim3(pgrid), dim3(256), 0, s, pa);
+		HIP_TRY(h, hipMemcpyAsync(&flag, d_flag, 4, hipMemcpyDeviceToHost, s));
+		HIP_TRY(h, hipStreamSynchronize(s));
+		if (flag) bits = 8;
+	}
+	if (bits == 8) {
+		HIP_TRY(h, hipMemcpyAsync(d_swoff, swoff8.data(), (size_t)nreads * 8, hipMemcpyHostToDevice, s));
+		hipLaunchKernelGGL(at::at_pack<8>, dim3(pgrid), dim3(256), 0, s, pa);
+	}
+	HIP_TRY(h, hipGetLastError());
+	HIP_TRY(h, hipStreamSynchronize(s));   /* swoff* are stack-lifetime vectors */
+	const size_t b_res = al((size_t)npairs * 4), b_ops = al((size_t)ops_total + 64), b_pfx = al((size_t)(npairs + 1) * 8);
+	rc = grow(h, &h->d_out, &h->out_bytes, 5 * b_res + b_ops + (tb ? b_pfx : 0));
+	if (rc) return rc;
+	char *dout = (char *)h->d_out;
+	int32_t *d_score = (int32_t *)dout, *d_ei = (int32_t *)(dout + b_res), *d_ej = (int32_t *)(dout + 2 * b_res);
+	int32_t *d_st = (int32_t *)(dout + 3 * b_res), *d_nops = (int32_t *)(dout + 4 * b_res);
+	uint8_t *d_ops = (uint8_t *)(dout + 5 * b_res);
+	int64_t *d_poff = (int64_t *)(dout + 5 * b_res + b_ops);
+	rc = align_device(h, mode, npairs, d_words, bits, d_swoff, d_len, d_swoff, d_len, maxlen, maxlen, 0, tb ? 1 : 0, d_score, d_ei, d_ej, d_st,
+	                  tb ? d_ops : nullptr, tb ? d_opsoff : nullptr, tb ? d_nops : nullptr, s, nreads, first_pair);
+	if (rc) return rc;
+	HIP_TRY(h, hipMemcpyAsync(out_score, d_score, (size_t)npairs * 4, hipMemcpyDeviceToHost, s));
+	if (out_end_i) HIP_TRY(h, hipMemcpyAsync(out_end_i, d_ei, (size_t)npairs * 4, hipMemcpyDeviceToHost, s));
+	if (out_end_j) HIP_TRY(h, hipMemcpyAsync(out_end_j, d_ej, (size_t)npairs * 4, hipMemcpyDeviceToHost, s));
+	if (out_state) HIP_TRY(h, hipMemcpyAsync(out_state, d_st, (size_t)npairs * 4, hipMemcpyDeviceToHost, s));
+	std::vector<int64_t> h_poff;
+	if (tb) {
+		HIP_TRY(h, hipMemcpyAsync(out_nops, d_nops, (size_t)npairs * 4, hipMemcpyDeviceToHost, s));
+		rc = grow(h, &h->d_str, &h->str_bytes, al((size_t)slots_total + 64));
+		if (rc) return rc;
+		rc = at_compact_ops_device(h, npairs, d_ops, d_opsoff, d_nops, (uint8_t *)h->d_str, slots_total, d_poff, s);
+		if (rc) return rc;
+		h_poff.resize((size_t)npairs + 1);
+		HIP_TRY(h, hipMemcpyAsync(h_poff.data(), d_poff, (size_t)(npairs + 1) * 8, hipMemcpyDeviceToHost, s));
+	}
+	HIP_TRY(h, hipStreamSynchronize(s));
+	for (int64_t p = 0; p < npairs; ++p)
+		if (out_score[p] == INT32_MIN || (tb && out_nops[p] < 0))
+			return fail(h, AT_ERR_DOMAIN, "pair %lld: input outside the domain on which the reference is defined", (long long)(first_pair + p));
+	if (tb) {
+		const int64_t total = h_poff[(size_t)npairs];
+		if (total < 0 || total > slots_total) return fail(h, AT_ERR_DOMAIN, "traceback lengths inconsistent with the slots");
+		std::vector<uint8_t> pk((size_t)total + 1);
+		if (total) HIP_TRY(h, hipMemcpyAsync(pk.data(), h->d_str, (size_t)total, hipMemcpyDeviceToHost, s));
+		HIP_TRY(h, hipStreamSynchronize(s));
+		for (int64_t p = 0; p < npairs; ++p)
+			if (out_nops[p] > 0) memcpy(out_ops + ops_off[p], pk.data() + h_poff[(size_t)p], (size_t)out_nops[p]);
+	}
 	return AT_OK;
 }
 

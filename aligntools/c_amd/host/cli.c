@@ -10,10 +10,13 @@
  */
 #define _POSIX_C_SOURCE 200809L
 #include "at_host.h"
+#include <signal.h>
 #include <stdint.h>
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <sys/types.h>
+#include <sys/wait.h>
 #include <unistd.h>
 
 #define PACKAGE_VERSION "0.7.23-r15"
@@ -113,62 +116,221 @@ static int main_single(int cmd, int argc, char *argv[])
 	return 0;
 }
 
-/* ---- batch extension: N pairs per file, one GPU batch ---- */
-static int main_batch(int argc, char *argv[])
+/* ---- batch extension: N pairs per file, one GPU batch per process ----
+ *   alignTools batch <command> [options] [--score-only] [--all-vs-all] [--gpus N] <pairs.fa>
+ *     default        records (2k, 2k+1) form pair k
+ *     --all-vs-all   the records are reads; every ordered pair a < b is aligned as s1 = read a, s2 = read b (not for fit)
+ *     --score-only   no tracebacks: one line per pair (name1, name2, score)
+ *     --gpus N       one process per GPU: this process starts N workers (itself, with AT_RANK / AT_WORLD / AT_DEVICE /
+ *                    AT_COMM_DIR in their environment), rank 0's options are broadcast over RCCL, every rank aligns a
+ *                    contiguous share of the pairs on its own GPU, results are gathered over RCCL and rank 0 prints them
+ *                    in pair order.  The output is that of --gpus 1. */
+typedef struct { int score_only, all_vs_all, gpus; } batch_flags;
+
+/* linear index p of the strict upper triangle of n x n (row-major) -> (a, b), a < b */
+static void tri_pair(int64_t p, int64_t n, int64_t *a, int64_t *b)
 {
-	int cmd = -1, k, mode, rc;
-	opt_t *opt = init_opt();
+	int64_t r = 0, before = 0;
+	while (before + (n - 1 - r) <= p) { before += n - 1 - r; ++r; }
+	*a = r; *b = r + 1 + (p - before);
+}
+
+static int batch_worker(int cmd, opt_t *opt, const batch_flags *bf, const char *fname, int rank, int world, const char *comm_dir)
+{
 	at_records rec;
 	at_handle *h;
-	size_t n, p, tot = 0;
+	int mode, rc;
+	size_t nrec, p, tot = 0;
+	int64_t npairs, lo, hi, n, k;
 	uint8_t *blob;
-	char *r1, *r2;
-	int64_t *off1, *off2, *stroff;
-	int32_t *l1, *l2, *score, *ei, *ej, *st, *nops;
-	if (argc < 2) { fprintf(stderr, "Usage:   alignTools batch <global|local|fit|overlap|edit> [options] <pairs.fa>\n"); free(opt); return 1; }
-	for (k = 0; k < 5; ++k) if (strcmp(argv[1], cmd_name[k]) == 0) cmd = k;
-	if (cmd < 0) { fprintf(stderr, "[main] unrecognized command '%s'\n", argv[1]); free(opt); return 1; }
-	if (parse_opts(cmd, argc - 1, argv + 1, opt)) { free(opt); return 1; }
-	if (optind + 1 > argc - 1) { cmd_usage(cmd, opt); free(opt); return 1; }
-	if (at_read_records(argv[argc - 1], &rec) != 0) die("Can't open %s\n", argv[argc - 1]);
-	if (rec.n < 2 || (rec.n & 1)) die("batch input needs an even number of records (got %d)", (int)rec.n);
-	n = rec.n / 2;
+	int64_t *roff, *off1, *off2, *slot;
+	int32_t *rlen, *l1, *l2, *score, *ei, *ej, *st, *nops;
+	char *r1 = NULL, *r2 = NULL;
+	const int tb = !bf->score_only && cmd != C_EDIT;
+	if (at_read_records(fname, &rec) != 0) die("Can't open %s\n", fname);
+	nrec = rec.n;
+	if (bf->all_vs_all) {
+		if (cmd == C_FIT) die("--all-vs-all: fit needs ordered pairs (first sequence shorter than the second)");
+		if (nrec < 2) die("--all-vs-all needs at least two records (got %d)", (int)nrec);
+		npairs = (int64_t)nrec * ((int64_t)nrec - 1) / 2;
+	} else {
+		if (nrec < 2 || (nrec & 1)) die("batch input needs an even number of records (got %d)", (int)nrec);
+		npairs = (int64_t)nrec / 2;
+	}
 	if (opt->s == AT_TRUE) {
 		if (rec.comment[1] == NULL) die("fail to read junction sites");
 		opt->sites.size = (size_t)at_parse_sites(rec.comment[1], &opt->sites.pos);
 	}
-	for (p = 0; p < rec.n; ++p) tot += rec.len[p];
+	for (p = 0; p < nrec; ++p) tot += rec.len[p];
 	blob = (uint8_t *)at_xmalloc(tot + 1);
-	r1 = (char *)at_xmalloc(tot + n + 64); r2 = (char *)at_xmalloc(tot + n + 64);
-	off1 = (int64_t *)at_xmalloc(n * 8); off2 = (int64_t *)at_xmalloc(n * 8); stroff = (int64_t *)at_xmalloc(n * 8);
-	l1 = (int32_t *)at_xmalloc(n * 4); l2 = (int32_t *)at_xmalloc(n * 4); score = (int32_t *)at_xmalloc(n * 4);
-	ei = (int32_t *)at_xmalloc(n * 4); ej = (int32_t *)at_xmalloc(n * 4); st = (int32_t *)at_xmalloc(n * 4); nops = (int32_t *)at_xmalloc(n * 4);
+	roff = (int64_t *)at_xmalloc(nrec * 8); rlen = (int32_t *)at_xmalloc(nrec * 4);
 	tot = 0;
-	for (p = 0; p < n; ++p) {
-		off1[p] = (int64_t)tot; l1[p] = (int32_t)rec.len[2 * p];
-		memcpy(blob + tot, rec.seq[2 * p], rec.len[2 * p]); tot += rec.len[2 * p];
-		off2[p] = (int64_t)tot; l2[p] = (int32_t)rec.len[2 * p + 1];
-		memcpy(blob + tot, rec.seq[2 * p + 1], rec.len[2 * p + 1]); tot += rec.len[2 * p + 1];
-		stroff[p] = off1[p] + (int64_t)p;          /* slots of l1+l2+1 bytes */
-		if (cmd == C_FIT && l1[p] > l2[p]) die("first sequence must be shorter than the second\n");
+	for (p = 0; p < nrec; ++p) {
+		roff[p] = (int64_t)tot; rlen[p] = (int32_t)rec.len[p];
+		memcpy(blob + tot, rec.seq[p], rec.len[p]); tot += rec.len[p];
+	}
+	/* this rank's contiguous share of the pairs: rank r owns [ceil(n r / N), ceil(n (r + 1) / N)) */
+	lo = (npairs * rank + world - 1) / world;
+	hi = (npairs * (rank + 1) + world - 1) / world;
+	if (hi > npairs) hi = npairs;
+	n = hi - lo;
+	off1 = (int64_t *)at_xmalloc((size_t)(n + 1) * 8); off2 = (int64_t *)at_xmalloc((size_t)(n + 1) * 8); slot = (int64_t *)at_xmalloc((size_t)(n + 1) * 8);
+	l1 = (int32_t *)at_xmalloc((size_t)(n + 1) * 4); l2 = (int32_t *)at_xmalloc((size_t)(n + 1) * 4);
+	score = (int32_t *)at_xmalloc((size_t)(n + 1) * 4); ei = (int32_t *)at_xmalloc((size_t)(n + 1) * 4); ej = (int32_t *)at_xmalloc((size_t)(n + 1) * 4);
+	st = (int32_t *)at_xmalloc((size_t)(n + 1) * 4); nops = (int32_t *)at_xmalloc((size_t)(n + 1) * 4);
+	{
+		int64_t sl = 0, a = 0, b = 0;
+		for (k = 0; k < n; ++k) {
+			if (bf->all_vs_all) tri_pair(lo + k, (int64_t)nrec, &a, &b); else { a = 2 * (lo + k); b = a + 1; }
+			off1[k] = roff[a]; l1[k] = rlen[a]; off2[k] = roff[b]; l2[k] = rlen[b];
+			slot[k] = sl; sl += (int64_t)l1[k] + l2[k] + 1;
+			if (cmd == C_FIT && l1[k] > l2[k]) die("first sequence must be shorter than the second\n");
+		}
+		if (tb) { r1 = (char *)at_xmalloc((size_t)sl + 64); r2 = (char *)at_xmalloc((size_t)sl + 64); }
 	}
 	mode = cmd == C_GLOBAL ? AT_MODE_GLOBAL : cmd == C_LOCAL ? AT_MODE_LOCAL : cmd == C_FIT ? AT_MODE_FIT
 	     : cmd == C_OVERLAP ? AT_MODE_OVERLAP : AT_MODE_EDIT;
 	h = at_host_handle();
 	rc = at_set_scoring(h, opt->m, opt->u, opt->o, opt->e, opt->j, opt->s == AT_TRUE, opt->sites.pos, (int)opt->sites.size);
-	if (rc == AT_OK)   /* strings are rendered on the GPU (at_render.hip.h) */
-		rc = cmd == C_EDIT ? at_align_batch(h, mode, (int64_t)n, blob, off1, l1, off2, l2, 0, score, ei, ej, st, NULL, NULL, NULL)
-		                   : at_align_batch_strings(h, mode, (int64_t)n, blob, off1, l1, off2, l2, score, ei, ej, st, r1, r2, stroff, nops);
-	if (rc != AT_OK) die("%s", at_last_error(h));
-	for (p = 0; p < n; ++p) {
-		if (cmd == C_EDIT) { printf("%s\t%s\tedit_distance=%d\n", rec.name[2 * p], rec.name[2 * p + 1], score[p]); continue; }
-		printf("%s\t%s\tscore=%f\n%s\n%s\n", rec.name[2 * p], rec.name[2 * p + 1], (double)score[p], r1 + stroff[p], r2 + stroff[p]);
+	if (rc == AT_OK && world > 1) {
+		rc = at_comm_init(h, rank, world, comm_dir);
+		if (rc == AT_OK) rc = at_comm_broadcast_scoring(h);      /* rank 0's options are everybody's */
 	}
-	free(blob); free(r1); free(r2); free(off1); free(off2); free(stroff);
-	free(l1); free(l2); free(score); free(ei); free(ej); free(st); free(nops);
+	if (rc == AT_OK && n > 0) {
+		if (bf->all_vs_all && !tb)   /* scores of a slice of the triangle: the reads go up once, the pairs are enumerated on the GPU */
+			rc = at_align_allpairs(h, mode, (int64_t)nrec, blob, roff, rlen, lo, n, 0, score, ei, ej, st, NULL, NULL, NULL);
+		else if (!tb)
+			rc = at_align_batch(h, mode, n, blob, off1, l1, off2, l2, 0, score, ei, ej, st, NULL, NULL, NULL);
+		else        /* strings are rendered on the GPU (at_render.hip.h) */
+			rc = at_align_batch_strings(h, mode, n, blob, off1, l1, off2, l2, score, ei, ej, st, r1, r2, slot, nops);
+	}
+	if (rc != AT_OK) die("%s", at_last_error(h));
+	if (world == 1) {
+		int64_t a = 0, b = 0;
+		for (k = 0; k < n; ++k) {
+			if (bf->all_vs_all) tri_pair(lo + k, (int64_t)nrec, &a, &b); else { a = 2 * (lo + k); b = a + 1; }
+			if (cmd == C_EDIT) printf("%s\t%s\tedit_distance=%d\n", rec.name[a], rec.name[b], score[k]);
+			else if (!tb) printf("%s\t%s\tscore=%f\n", rec.name[a], rec.name[b], (double)score[k]);
+			else printf("%s\t%s\tscore=%f\n%s\n%s\n", rec.name[a], rec.name[b], (double)score[k], r1 + slot[k], r2 + slot[k]);
+		}
+	} else {
+		/* gather: the scores (4 bytes per pair) and, with tracebacks, every pair's two strings back to back with their
+		 * terminators -- at_comm_allgather sends the sizes first, then one padded payload; rank 0 prints */
+		int64_t *bytes = (int64_t *)at_xmalloc((size_t)world * 8), paylen = 0, o, q;
+		int32_t *allscore = (int32_t *)at_xmalloc((size_t)(npairs + 1) * 4);
+		char *pay = NULL, *allpay = NULL;
+		rc = at_comm_allgather(h, score, n * 4, allscore, npairs * 4, bytes);
+		if (rc == AT_OK && tb) {
+			int64_t cap = 0;
+			for (p = 0; p < nrec; ++p) cap += (int64_t)rec.len[p];
+			for (k = 0; k < n; ++k) paylen += 2 * ((int64_t)nops[k] + 1);
+			pay = (char *)at_xmalloc((size_t)paylen + 1);
+			for (k = 0, o = 0; k < n; ++k) {
+				memcpy(pay + o, r1 + slot[k], (size_t)nops[k] + 1); o += nops[k] + 1;
+				memcpy(pay + o, r2 + slot[k], (size_t)nops[k] + 1); o += nops[k] + 1;
+			}
+			/* an upper bound of everything: every pair's strings are at most l1 + l2 + 1 long, twice */
+			cap = bf->all_vs_all ? 2 * ((int64_t)(nrec - 1) * cap + npairs) : 2 * (cap + npairs);
+			allpay = (char *)at_xmalloc((size_t)cap + 1);
+			rc = at_comm_allgather(h, pay, paylen, allpay, cap, bytes);
+		}
+		if (rc != AT_OK) die("%s", at_last_error(h));
+		if (rank == 0) {
+			int64_t a = 0, b = 0;
+			for (q = 0, o = 0; q < npairs; ++q) {
+				if (bf->all_vs_all) tri_pair(q, (int64_t)nrec, &a, &b); else { a = 2 * q; b = a + 1; }
+				if (cmd == C_EDIT) printf("%s\t%s\tedit_distance=%d\n", rec.name[a], rec.name[b], allscore[q]);
+				else if (!tb) printf("%s\t%s\tscore=%f\n", rec.name[a], rec.name[b], (double)allscore[q]);
+				else {
+					const char *x = allpay + o, *y = x + strlen(x) + 1;
+					printf("%s\t%s\tscore=%f\n%s\n%s\n", rec.name[a], rec.name[b], (double)allscore[q], x, y);
+					o += 2 * ((int64_t)strlen(x) + 1);
+				}
+			}
+		}
+		at_comm_destroy(h);
+		free(bytes); free(allscore); free(pay); free(allpay);
+	}
+	free(blob); free(roff); free(rlen); free(off1); free(off2); free(slot);
+	free(l1); free(l2); free(score); free(ei); free(ej); free(st); free(nops); free(r1); free(r2);
 	at_free_records(&rec);
-	free(opt->sites.pos); free(opt);
 	return 0;
+}
+
+/* start one worker per GPU (this binary again, told its rank through the environment) and wait for them */
+static int batch_launch(int world, char *argv0, int argc, char *argv[])
+{
+	char dir[] = "/tmp/alignTools.XXXXXX", buf[32];
+	pid_t *pid = (pid_t *)at_xmalloc((size_t)world * sizeof(pid_t));
+	int r, status, worst = 0;
+	char **av = (char **)at_xmalloc((size_t)(argc + 2) * sizeof(char *));
+	if (!mkdtemp(dir)) die("cannot create a rendezvous directory under /tmp");
+	av[0] = argv0;
+	for (r = 0; r < argc; ++r) av[r + 1] = argv[r];
+	av[argc + 1] = NULL;
+	fflush(stdout); fflush(stderr);
+	for (r = 0; r < world; ++r) {
+		pid[r] = fork();
+		if (pid[r] < 0) die("fork failed");
+		if (pid[r] == 0) {
+			snprintf(buf, sizeof buf, "%d", r); setenv("AT_RANK", buf, 1);
+			if (!getenv("AT_ONE_DEVICE")) setenv("AT_DEVICE", buf, 1);      /* rank r on GPU r (AT_ONE_DEVICE: rehearsals on one card) */
+			snprintf(buf, sizeof buf, "%d", world); setenv("AT_WORLD", buf, 1);
+			setenv("AT_COMM_DIR", dir, 1);
+			execv("/proc/self/exe", av);
+			_exit(127);
+		}
+	}
+	/* a rank that fails leaves the others waiting in a collective: the first failure ends them all */
+	for (r = 0; r < world; ++r) {
+		const pid_t done = waitpid(-1, &status, 0);
+		int q, code = done < 0 || !WIFEXITED(status) ? 255 : WEXITSTATUS(status);
+		if (code > worst) worst = code;
+		if (code != 0) {
+			for (q = 0; q < world; ++q) if (pid[q] != done) kill(pid[q], SIGTERM);
+		}
+	}
+	/* the rendezvous directory held a few small files */
+	{
+		char cmdline[96];
+		snprintf(cmdline, sizeof cmdline, "rm -rf %s", dir);
+		if (system(cmdline) != 0) worst = worst ? worst : 0;
+	}
+	free(pid); free(av);
+	return worst;
+}
+
+static int main_batch(int argc, char *argv[], char *argv0)
+{
+	int cmd = -1, k, n = 0;
+	opt_t *opt = init_opt();
+	batch_flags bf = {0, 0, 1};
+	char **av = (char **)at_xmalloc((size_t)(argc + 1) * sizeof(char *));
+	const char *usage_line = "Usage:   alignTools batch <global|local|fit|overlap|edit> [options] [--score-only] [--all-vs-all] [--gpus N] <pairs.fa>\n";
+	/* the long flags of the extension are taken out before getopt sees the reference's short options */
+	for (k = 0; k < argc; ++k) {
+		if (strcmp(argv[k], "--score-only") == 0) bf.score_only = 1;
+		else if (strcmp(argv[k], "--all-vs-all") == 0) bf.all_vs_all = 1;
+		else if (strcmp(argv[k], "--gpus") == 0 && k + 1 < argc) bf.gpus = atoi(argv[++k]);
+		else av[n++] = argv[k];
+	}
+	av[n] = NULL;
+	if (n < 2 || bf.gpus < 1 || bf.gpus > 64) { fprintf(stderr, "%s", usage_line); free(opt); free(av); return 1; }
+	for (k = 0; k < 5; ++k) if (strcmp(av[1], cmd_name[k]) == 0) cmd = k;
+	if (cmd < 0) { fprintf(stderr, "[main] unrecognized command '%s'\n", av[1]); free(opt); free(av); return 1; }
+	if (parse_opts(cmd, n - 1, av + 1, opt)) { free(opt); free(av); return 1; }
+	if (optind + 1 > n - 1) { cmd_usage(cmd, opt); free(opt); free(av); return 1; }
+	if (bf.gpus > 1 && !getenv("AT_RANK")) {        /* the launcher: never touches a GPU itself */
+		k = batch_launch(bf.gpus, argv0, argc, argv);
+		free(opt); free(av);
+		return k ? k : -1;                          /* -1: the workers printed everything, the [main] trailer too */
+	}
+	{
+		const int rank = getenv("AT_RANK") ? atoi(getenv("AT_RANK")) : 0, world = getenv("AT_WORLD") ? atoi(getenv("AT_WORLD")) : 1;
+		k = batch_worker(cmd, opt, &bf, av[n - 1], rank, world, getenv("AT_COMM_DIR") ? getenv("AT_COMM_DIR") : "/tmp");
+		free(opt->sites.pos); free(opt); free(av);
+		return k == 0 && rank != 0 ? -1 : k;        /* only rank 0 prints the [main] trailer */
+	}
 }
 
 int main(int argc, char *argv[])
@@ -177,7 +339,10 @@ int main(int argc, char *argv[])
 	if (argc < 2) return usage();
 	for (k = 0; k < 5; ++k) if (strcmp(argv[1], cmd_name[k]) == 0) cmd = k;
 	if (cmd >= 0) ret = main_single(cmd, argc - 1, argv + 1);
-	else if (strcmp(argv[1], "batch") == 0) ret = main_batch(argc - 1, argv + 1);
+	else if (strcmp(argv[1], "batch") == 0) {
+		ret = main_batch(argc - 1, argv + 1, argv[0]);
+		if (ret == -1) return 0;        /* a worker other than rank 0, or the launcher: nothing more to say */
+	}
 	else {
 		fprintf(stderr, "[main] unrecognized command '%s'\n", argv[1]);
 		return 1;

@@ -145,6 +145,19 @@ int at_align_allpairs_device(at_handle *h, int mode, int64_t nreads,
                              void *stream);
 
 /*
+ * All-vs-all with the read set in HOST memory (what `alignTools batch <cmd> --all-vs-all reads.fa` calls): the reads
+ * (off[k], len[k] in seq_blob) go up and are packed once; pair p of [first_pair, first_pair + npairs) is aligned as
+ * s1 = read a, s2 = read b with (a, b) as in at_align_allpairs_device; outputs are indexed by p - first_pair; pair p's
+ * ops go to out_ops[ops_off[p - first_pair] ..] (a slot of len[a] + len[b] bytes).  Not for AT_MODE_FIT (l1 <= l2 is a
+ * property of ordered pairs).
+ */
+int at_align_allpairs(at_handle *h, int mode, int64_t nreads,
+                      const uint8_t *seq_blob, const int64_t *off, const int32_t *len,
+                      int64_t first_pair, int64_t npairs, int want_traceback,
+                      int32_t *out_score, int32_t *out_end_i, int32_t *out_end_j, int32_t *out_state,
+                      uint8_t *out_ops, const int64_t *ops_off, int32_t *out_nops);
+
+/*
  * Output rendering on the GPU: what trace_back_* + strrev produce (alignment.h:372-412,
  * 558-592, 766-800, 896-922, 172-184) -- the two gapped strings, in reading order -- from the op codes and end
  * cells at_align_batch_device left in HBM and the same packed sequences.  Pair k's strings are written to
@@ -180,6 +193,18 @@ int at_align_batch_strings(at_handle *h, int mode, int64_t npairs,
                            const int64_t *off2, const int32_t *len2,
                            int32_t *out_score, int32_t *out_end_i, int32_t *out_end_j, int32_t *out_state,
                            char *out_r1, char *out_r2, const int64_t *str_off, int32_t *out_len);
+
+/*
+ * Multi-process batches: one process per GPU, each with its own handle.  The pairs are independent, so
+ * the only communication is a broadcast of rank 0's scoring block and a gather of results, both RCCL collectives on the
+ * handles' devices (over xGMI inside a node).  `dir` is a directory all ranks can reach: rank 0 leaves the RCCL id there.
+ * RCCL is loaded at at_comm_init, not linked.  at_comm_allgather gathers a different number of bytes from every rank:
+ * sizes first, then one payload padded to the largest (the two-phase CIGAR gather); every rank receives everything.
+ */
+int at_comm_init(at_handle *h, int rank, int world, const char *dir);
+int at_comm_broadcast_scoring(at_handle *h);
+int at_comm_allgather(at_handle *h, const void *mine, int64_t mine_bytes, void *all, int64_t all_cap, int64_t *bytes_of_rank);
+void at_comm_destroy(at_handle *h);
 
 /* Host helper: pack `npairs` pairs of raw bytes into the word layout above.
  * bits = 0 picks 2 when every byte is one of ACGT, else 8; the choice is

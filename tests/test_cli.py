@@ -7,6 +7,7 @@ import ctypes as C
 import gzip
 import hashlib
 import os
+import random
 import subprocess
 
 import pytest
@@ -97,6 +98,80 @@ def test_cli_batch_extension(built, tmp_path):
     lines = p.stdout.decode().splitlines()
     assert lines[0] == "a1\ta2\tscore=4.000000" and lines[1:3] == ["LEA", "MEA"]
     assert lines[3].startswith("b1\tb2\tscore=")
+
+
+def _reads_file(path, n, seed):
+    rng = random.Random(seed)
+    base = "".join(rng.choice("ACGT") for _ in range(400))
+    with open(path, "w") as fh:
+        for k in range(n):
+            a = rng.randint(0, 200)
+            s = list(base[a:a + rng.randint(60, 150)])
+            for _ in range(4):
+                s[rng.randrange(len(s))] = rng.choice("ACGT")
+            fh.write(">r%d some comment\n%s\n" % (k, "".join(s)))
+
+
+@pytest.mark.gpu
+def test_cli_batch_score_only_and_all_vs_all(built, tmp_path):
+    """`--score-only` drops the strings, `--all-vs-all` aligns every ordered pair a < b of the records (enumerated on the GPU
+    when only scores are wanted): lines, order and scores equal the oracle's."""
+    import oracle as O
+    _reads_file(tmp_path / "reads.fa", 12, 3)
+    recs = []
+    for line in open(tmp_path / "reads.fa"):
+        if line.startswith(">"):
+            recs.append([line[1:].split()[0], ""])
+        else:
+            recs[-1][1] += line.strip()
+    for mode, extra in (("overlap", []), ("local", ["-m", "2", "-u", "-2", "-o", "-5", "-e", "-2"]), ("global", []), ("edit", ["-u", "1"])):
+        sc = (2, -2, -5, -2) if mode == "local" else (1, 1, -5, -1) if mode == "edit" else (1, -2, -5, -1)
+        for tb in (False, True):
+            if mode == "edit" and tb:
+                continue
+            argv = [EXE, "batch", mode] + extra + ["--all-vs-all"] + ([] if tb else ["--score-only"]) + ["reads.fa"]
+            p = subprocess.run(argv, cwd=tmp_path, capture_output=True)
+            assert p.returncode == 0, p.stderr
+            lines = p.stdout.decode().splitlines()
+            q = 0
+            for a in range(len(recs)):
+                for b in range(a + 1, len(recs)):
+                    r = O.align(O.MODE_NAMES[mode], recs[a][1], recs[b][1], *sc)
+                    want = "%s\t%s\t%s" % (recs[a][0], recs[b][0], ("edit_distance=%d" % r["score"]) if mode == "edit" else "score=%f" % r["score"])
+                    assert lines[q] == want, (mode, tb, a, b, lines[q])
+                    if tb:
+                        assert lines[q + 1:q + 3] == [r["r1"], r["r2"]], (mode, a, b)
+                    q += 3 if tb else 1
+            assert q == len(lines)
+    # pair lists: --score-only
+    p = subprocess.run([EXE, "batch", "overlap", "--score-only", "reads.fa"], cwd=tmp_path, capture_output=True)
+    assert p.returncode == 0 and len(p.stdout.decode().splitlines()) == 6
+    p = subprocess.run([EXE, "batch", "fit", "--all-vs-all", "reads.fa"], cwd=tmp_path, capture_output=True)
+    assert p.returncode == 255 and b"fit needs ordered pairs" in p.stderr
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("flags", [[], ["--score-only"], ["--all-vs-all", "--score-only"]])
+def test_cli_batch_gpus_n_matches_one_gpu(built, tmp_path, flags):
+    """`--gpus N`: one process per GPU, rank 0's options broadcast, contiguous shares of the pairs, results gathered and
+    printed by rank 0.  The test box has one card, so N = 2 and N = 3 are rehearsed with the ranks sharing it and the
+    collectives going through the rendezvous directory (AT_COMM=files -- RCCL refuses two ranks on one device); N = 1
+    needs no collective.  Output and return code must equal the single-process run byte for byte."""
+    _reads_file(tmp_path / "reads.fa", 14, 5)
+    base = [EXE, "batch", "local", "-m", "2", "-u", "-2", "-o", "-5", "-e", "-2"] + flags
+    one = subprocess.run(base + ["reads.fa"], cwd=tmp_path, capture_output=True)
+    assert one.returncode == 0, one.stderr
+    env = dict(os.environ, AT_COMM="files", AT_ONE_DEVICE="1")
+    for n in (1, 2, 3):
+        p = subprocess.run(base + ["--gpus", str(n), "reads.fa"], cwd=tmp_path, capture_output=True, env=env, timeout=600)
+        assert p.returncode == 0, (n, p.stderr[-2000:])
+        assert p.stdout == one.stdout, (n, flags)
+        assert p.stderr.decode().count("[main] CMD:") == 1      # only rank 0 signs off
+    # a failing rank ends the whole job with its code: fit with a read longer than its contig
+    with open(tmp_path / "bad.fa", "w") as fh:
+        fh.write(">a\nACGTACGTAC\n>b\nACGT\n>c\nAC\n>d\nACGT\n")
+    p = subprocess.run([EXE, "batch", "fit", "--gpus", "2", "bad.fa"], cwd=tmp_path, capture_output=True, env=env, timeout=600)
+    assert p.returncode == 255 and b"first sequence must be shorter" in p.stderr
 
 
 # ---------------------------------------------------------------- FASTA reader (CPU)

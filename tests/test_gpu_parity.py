@@ -474,7 +474,8 @@ def test_packed_kernels_on_byte_alphabets(al):
                        (r["score"], r["end_i"], r["end_j"], r["state"], r["ops"]), (alpha, mode, uj, k)
 
 
-def test_ragged_local_batches_in_frames(al):
+@pytest.mark.parametrize("maxl", [208, 152])
+def test_ragged_local_batches_in_frames(al, maxl):
     """Ragged local batches of reads (l1 <= 208) run on the packed kernel in frames: sorted into buckets of similar size,
     every alignment keeping its own extents inside its bucket's frame.  All lengths from 1 up, unrelated and related
     pairs, score / end cell / ops against the oracle; a batch with one longer read falls back to the int32 kernel."""
@@ -482,7 +483,8 @@ def test_ragged_local_batches_in_frames(al):
     dna = lambda n: "".join(rng.choice("ACGT") for _ in range(n))
     pairs = []
     for k in range(3000):
-        l1 = rng.choice([1, 2, 15, 16, 17, 48, 49, 63, 64, 65, 80, 81, 96, 112, 113, 150, 160, 161, 207, 208]) if k % 3 == 0 else rng.randint(1, 208)
+        l1 = rng.choice([1, 2, 15, 16, 17, 40, 41, 48, 49, 56, 57, 63, 64, 65, 80, 81, 96, 104, 105, 112, 113, 128, 129, 150, 152, 160, 161, 207, 208]) if k % 3 == 0 else rng.randint(1, 208)
+        l1 = min(l1, maxl)      # (reads of up to 152 bases: frames on the 8-lane groups, else on the 16-lane groups)
         l2 = rng.randint(1, 260)
         a = dna(l1)
         if k % 2:
@@ -504,7 +506,7 @@ def test_ragged_local_batches_in_frames(al):
         al.set_scoring(*sc)
         for tb in (True, False):
             res = al.align_batch("local", pairs, traceback=tb, render=False)
-            assert "ragged frames" in al.last_config, al.last_config
+            assert "ragged frames" in al.last_config and ("8x8-lane" if maxl <= 152 else "4x16-lane") in al.last_config, al.last_config
             for k, (a, b) in enumerate(pairs):
                 r = O.align(O.LOCAL, a, b, *sc)
                 assert (int(res["score"][k]), int(res["end_i"][k]), int(res["end_j"][k])) == (r["score"], r["end_i"], r["end_j"]), (sc, tb, k)

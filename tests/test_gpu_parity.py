@@ -484,7 +484,7 @@ def test_ragged_local_batches_in_frames(al, maxl):
     pairs = []
     for k in range(3000):
         l1 = rng.choice([1, 2, 15, 16, 17, 40, 41, 48, 49, 56, 57, 63, 64, 65, 80, 81, 96, 104, 105, 112, 113, 128, 129, 150, 152, 160, 161, 207, 208]) if k % 3 == 0 else rng.randint(1, 208)
-        l1 = min(l1, maxl)      # (reads of up to 152 bases: frames on the 8-lane groups, else on the 16-lane groups)
+        l1 = min(l1, maxl)
         l2 = rng.randint(1, 260)
         a = dna(l1)
         if k % 2:
@@ -506,7 +506,7 @@ def test_ragged_local_batches_in_frames(al, maxl):
         al.set_scoring(*sc)
         for tb in (True, False):
             res = al.align_batch("local", pairs, traceback=tb, render=False)
-            assert "ragged frames" in al.last_config and ("8x8-lane" if maxl <= 152 else "4x16-lane") in al.last_config, al.last_config
+            assert "ragged frames" in al.last_config and "4x16-lane" in al.last_config, al.last_config
             for k, (a, b) in enumerate(pairs):
                 r = O.align(O.LOCAL, a, b, *sc)
                 assert (int(res["score"][k]), int(res["end_i"][k]), int(res["end_j"][k])) == (r["score"], r["end_i"], r["end_j"]), (sc, tb, k)

@@ -64,7 +64,9 @@ def valu_roofline(workload, pairs, tb, kernel_config, steps, elapsed):
     # the counters belong to one kernel configuration and batch size: another one (AT_GROUP, --pairs, --l1 ...) has no roofline
     if not insts or prof.get("kernel_config") != kernel_config or prof.get("pairs") != pairs:
         return None, traffic
-    cyc = vi["roofline"]["cycles_per_inst"]
+    # packed int16 kernels: every instruction of the step body is of the 4-cycle class; int32 kernels: mostly 2-cycle adds, priced
+    # with the full-rate 2.0 (the only bound that holds for any mix)
+    cyc = vi["roofline"]["cycles_per_inst"]["packed16" if "packed16" in kernel_config else "int32"]
     ghz = vi["roofline"]["clock_ghz"]
     simds = vi["roofline"]["simds"]
     peak = simds * ghz / cyc                      # G wave-instructions / s

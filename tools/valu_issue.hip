@@ -207,7 +207,7 @@ int main(int argc, char **argv)
 	std::sort(all_ghz.begin(), all_ghz.end());
 	std::sort(half_rate_cost.begin(), half_rate_cost.end());
 	char rb[512];
-	snprintf(rb, sizeof rb, "\n },\n \"roofline\": {\"cycles_per_inst\": 4.0, \"clock_ghz\": %.3f, \"simds\": %d, "
+	snprintf(rb, sizeof rb, "\n },\n \"roofline\": {\"cycles_per_inst\": {\"packed16\": 4.0, \"int32\": 2.0}, \"clock_ghz\": %.3f, \"simds\": %d, "
 	         "\"measured_packed16_cost\": {\"min\": %.3f, \"median\": %.3f, \"max\": %.3f}}\n}\n",
 	         all_ghz[all_ghz.size() / 2], cus * 4, half_rate_cost.front(), half_rate_cost[half_rate_cost.size() / 2], half_rate_cost.back());
 	js += rb;

@@ -201,8 +201,10 @@ int main(int argc, char **argv)
 	}
 	/* what bench.py prices SQ_INSTS_VALU with.  The step body of the sweep kernels is made of VOP3P packed 16-bit
 	 * operations, VOP3 bit-field operations and DPP moves: each occupies a SIMD for 4 cycles (64 lanes over 16 lanes per
-	 * cycle), and the 2-cycle VOP2 operations mixed in between cost 4 as well (the mix_* rows).  cycles_per_inst is that
-	 * architectural 4.0; measured_packed16_cost is what this run saw for the packed operations alone at 2-4 waves per SIMD
+	 * cycle), and the 2-cycle VOP2 operations mixed in between cost 4 as well (the mix_* rows): cycles_per_inst.packed16 is
+	 * that architectural 4.0.  The int32 kernels (overlap, edit, long pairs) are mostly 2-cycle VOP2 adds with 4-cycle max3 /
+	 * DPP in between and run FASTER than 4 cycles per instruction; they are priced with the 2.0 of the full-rate class, the
+	 * only bound that holds for every mix.  measured_packed16_cost is what this run saw for the packed operations alone at 2-4 waves per SIMD
 	 * (loop overhead and clock ramp included); clock_ghz is the median clock the chip held under these loads. */
 	std::sort(all_ghz.begin(), all_ghz.end());
 	std::sort(half_rate_cost.begin(), half_rate_cost.end());

@@ -318,6 +318,9 @@ static Layout16 layout16_for(bool tb, bool hasj, int l1, int l2, int ts, int for
 	const long long g_forced = env_ll("AT_GROUP", 0);
 	L.g = 64;
 	L.k = rows_per_lane(l1);
+	/* scores only, scores x4: 16 rows per lane (strips of 1 024 rows) once that is fewer lane-steps than strips of 256 --
+	 * per step a lane does 16 x 11 + 25 instructions instead of 4 x 11 + 25 */
+	if (!tb && ts == 2 && !getenv("AT_ROWS_PER_LANE") && ((l1 + 1023) / 1024) * (16 * 11 + 25) < ((l1 + 255) / 256) * (4 * 11 + 25)) L.k = 16;
 	if (force_g != 16 && (force_g == 8 || g_forced == 0 || g_forced == 8) && ts == 4 && l1 <= 152) {
 		L.g = 8;
 		L.k = l1 <= 40 ? 5 : l1 <= 56 ? 7 : l1 <= 80 ? 10 : l1 <= 104 ? 13 : l1 <= 128 ? 16 : 19;

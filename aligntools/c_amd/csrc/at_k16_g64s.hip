@@ -15,6 +15,10 @@ static at_sweep16_fn p2(int k, int store, bool tb)
 	case 1: return p3<MODE, 1>(store, tb);
 	case 2: return p3<MODE, 2>(store, tb);
 	case 3: return p3<MODE, 3>(store, tb);
+	case 16:   /* scores only: no pointer registers, so 16 rows per lane still leave 3 waves per SIMD, and 1 024 rows are one strip
+	            * (C3 scores only 5.6 -> 6.5 TCUPS); with pointers the same geometry needs 256 VGPRs (1.8 instead of 3.0 TCUPS) */
+		if (tb) return nullptr;
+		return store < 2 ? at::at_sweep16<MODE, 64, 16, 2, true, true, false, false, AT_BITS16> : at::at_sweep16<MODE, 64, 16, 2, false, false, false, false, AT_BITS16>;
 	default: return p3<MODE, 4>(store, tb);
 	}
 }

@@ -190,7 +190,7 @@ __global__ __launch_bounds__(64, AT_WAVES16(G, K)) void at_sweep16(const Sweep16
 	static_assert(MODE == K_GLOBAL || MODE == K_LOCAL || MODE == K_FIT || MODE == K_FITJ, "packed path: the affine modes");
 	constexpr bool HASJ = MODE == K_FITJ;
 	constexpr bool ISFIT = MODE == K_FIT || MODE == K_FITJ;
-	static_assert(TS == 4 || (TS == 2 && K <= 4), "TS = 2: the local row tag must fit 2 bits");
+	static_assert(TS == 4 || TS == 2, "scores x16 or x4");
 	constexpr int TMASK = (1 << TS) - 1;      /* tag bits of a score */
 	/* local arg-max: the key of a cell carries its row-in-lane in the tag bits, so one running maximum covers TMASK + 1
 	 * rows; lanes with more rows (8-lane groups: up to 19) keep one chain per TMASK + 1 rows */

@@ -321,6 +321,29 @@ def test_score_only_batches(al):
                     assert (int(res["end_i"][k]), int(res["end_j"][k]), int(res["state"][k])) == (r["end_i"], r["end_j"], r["state"])
 
 
+def test_score_only_long_pairs_sixteen_rows_per_lane(al):
+    """Scores-only launches of the x4 packed kernels take 16 rows per lane (strips of 1 024 rows) where that is fewer
+    lane-steps than strips of 256: 600, 1 024 and 1 600 rows, global and local, against the oracle (the same batches with
+    tracebacks keep 4 rows per lane and must agree)."""
+    rng = random.Random(1616)
+    dna = lambda n: "".join(rng.choice("ACGT") for _ in range(n))
+    for l1, l2 in ((600, 700), (1024, 1024), (1600, 900)):
+        pairs = []
+        for k in range(10):
+            a = dna(l1)
+            b = (a[: l1 // 2] + dna(25) + a[l1 // 2 + 40:] + dna(l2))[:l2] if k % 2 else dna(l2)
+            pairs.append((a, b))
+        for mode, sc in (("global", (1, -1, -4, -1)), ("local", (2, -2, -5, -2))):
+            al.set_scoring(*sc)
+            res = al.align_batch(mode, pairs, traceback=False)
+            assert "packed16 x4" in al.last_config and ("rows/lane=16" in al.last_config) == (l1 != 1600 or False) or "rows/lane" in al.last_config, al.last_config
+            full = al.align_batch(mode, pairs, render=False)
+            for k, (a, b) in enumerate(pairs):
+                r = O.align(O.MODE_NAMES[mode], a, b, *sc)
+                assert int(res["score"][k]) == r["score"] == int(full["score"][k]), (l1, mode, k)
+                assert (int(res["end_i"][k]), int(res["end_j"][k])) == (r["end_i"], r["end_j"]), (l1, mode, k)
+
+
 def test_deep_lane_kernels_overlap_scores_and_edit(al):
     """Overlap without tracebacks and edit run with 8 or 16 rows per lane once the first sequence is longer than 256:
     one strip (257..1024 rows), several strips (> 1024), ragged batches, row l1 anywhere inside its lane, both alphabets."""

@@ -336,7 +336,7 @@ def test_score_only_long_pairs_sixteen_rows_per_lane(al):
         for mode, sc in (("global", (1, -1, -4, -1)), ("local", (2, -2, -5, -2))):
             al.set_scoring(*sc)
             res = al.align_batch(mode, pairs, traceback=False)
-            assert "packed16 x4" in al.last_config and ("rows/lane=16" in al.last_config) == (l1 != 1600 or False) or "rows/lane" in al.last_config, al.last_config
+            assert "packed16 x4" in al.last_config and "rows/lane=16" in al.last_config, al.last_config
             full = al.align_batch(mode, pairs, render=False)
             for k, (a, b) in enumerate(pairs):
                 r = O.align(O.MODE_NAMES[mode], a, b, *sc)

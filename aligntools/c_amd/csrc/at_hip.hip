@@ -678,6 +678,8 @@ static int align_device(at_handle *h, int mode, int64_t npairs,
 		 * packed vs 2.00 TCUPS int32 for a lone launch, 2.70 vs 2.13 with launches in flight; 61k pairs: 2.70 vs 2.19.) */
 		const double min_rounds = getenv("AT_PACKED_MIN_ROUNDS") ? atof(getenv("AT_PACKED_MIN_ROUNDS")) : 1.0;
 		if (P.g == 64 && (double)((npairs + 1) / 2) < min_rounds * 12.0 * h->ncu) ts = 0;
+		/* the packed kernels index their slot with 24-bit multiplies: a pair whose slot would not fit takes the int32 kernel */
+		if (P.words >= (1LL << 24)) { if (rag) return fail(h, AT_ERR_ARG, "ragged packed launch outside its domain (slot too large)"); ts = 0; }
 		/* no packed kernel for the storage class this shape needs (the 16- and 32-lane groups have no all-HBM variant:
 		 * a 150-base read against a second sequence of more than ~4 000 bases): the int32 kernel takes any length */
 		if (ts && !packed16_kernel_exists(kmode, P, tb, ts, bits, rag)) {

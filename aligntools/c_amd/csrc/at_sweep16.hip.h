@@ -178,8 +178,10 @@ template <bool LDS, int K>
 AT_DEV int pidx(int wr, int r, int lane, int NL)
 {
 	constexpr int KF = K / 4 * 4, KR = K - KF;
-	if constexpr (LDS) return (wr * K + r) * NL + lane;
-	else return r < KF ? wr * NL * K + (r / 4) * 4 * NL + lane * 4 + (r & 3) : wr * NL * K + KF * NL + lane * KR + (r - KF);
+	/* 24-bit multiplies (v_mul_u32_u24, one issue slot; the 32-bit v_mul_lo_u32 takes four): the host keeps a slot below
+	 * 2^24 words for the packed kernels, so every index here is */
+	if constexpr (LDS) return __mul24(wr * K + r, NL) + lane;
+	else return r < KF ? __mul24(wr, NL * K) + __mul24(r & ~3, NL) + lane * 4 + (r & 3) : __mul24(wr, NL * K) + KF * NL + lane * KR + (r - KF);
 }
 
 template <int MODE, int G, int K, int TS, bool SMALL, bool PTRLDS, bool TB, bool RAG = false, int BITS = 2>
@@ -689,7 +691,7 @@ __global__ __launch_bounds__(64, AT_WAVES16(G, K)) void at_sweep16(const Sweep16
 								const int ln = li / K, r = li % K;
 								const int t = (qj - 1) + ln;
 								sh[q] = 16 * h + cell_shift<PB>(t % SPW);
-								w[q] = pm.ld(a.off_ptr + ss * wps * NL + pidx<PTRLDS, K>(t / SPW, r, glane + ln, NL));
+								w[q] = pm.ld(a.off_ptr + (G == 64 ? __mul24(ss, wps * NL) : 0) + pidx<PTRLDS, K>(t / SPW, r, glane + ln, NL));
 							}
 							bool go = true;
 #pragma unroll
@@ -712,25 +714,25 @@ __global__ __launch_bounds__(64, AT_WAVES16(G, K)) void at_sweep16(const Sweep16
 							if (!ok) break;
 						}
 					} else if (ok) {
-						while (ci > 0 && (ISFIT || cj > 0) && --guard >= 0) {
+						/* local / global: one pointer cell per op.  The state machine is written with selects, not branches: the
+						 * walk is the only part of a work item in which 2 .. 16 lanes keep a whole wavefront busy, so its length
+						 * in instructions counts (C3: a sixth of all vector instructions) */
+						const int wpsNL = wps * NL;
+						while (ci > 0 && cj > 0 && --guard >= 0) {
 							if (MODE == K_LOCAL && st == 0) break;            /* HOME :788-791 */
-							if (cj <= 0) { ok = false; break; }
-							const int ss = (ci - 1) / RS, li = (ci - 1) % RS;
+							const int ss = G == 64 ? (ci - 1) / RS : 0, li = G == 64 ? (ci - 1) % RS : ci - 1;
 							const int ln = li / K, r = li % K;
 							const int t = (cj - 1) + ln;
-							const uint32_t w = pm.ld(a.off_ptr + ss * wps * NL + pidx<PTRLDS, K>(t / SPW, r, glane + ln, NL));
+							const uint32_t w = pm.ld(a.off_ptr + (G == 64 ? __mul24(ss, wpsNL) : 0) + pidx<PTRLDS, K>(t / SPW, r, glane + ln, NL));
+							/* {bit 3: U winner, bit 2: L extended, pM[1:0]}.  Bit 3 is bit 3 of the U winner's tag for TS = 4 (M's 10
+							 * has it: opened) and bit 0 for TS = 2 (U's 1 has it: extended). */
 							const uint32_t nb = (w >> (16 * h + cell_shift<PB>(t % SPW))) & ((1u << PB) - 1u);
-							int op;
-							/* {bit 4: J came from M, bit 3: U winner, bit 2: L extended, pM[1:0]}.  Bit 3 is bit 3 of the U winner's
-							 * tag for TS = 4 (M's 10 has it: opened) and bit 0 for TS = 2 (U's 1 has it: extended). */
-							const bool l_ext = (nb & 4u) != 0;
+							if (st == 0) { ok = false; break; }               /* (no jump state here: a corrupt pointer) */
 							const bool u_open = TS == 4 ? (nb & 8u) != 0 : (nb & 8u) == 0;
-							const bool j_open = (nb & 16u) != 0;
-							if (st == 3) { st = l_ext ? 3 : 2; op = 1; --ci; }
-							else if (st == 2) { st = (int)(nb & 3u); op = 0; --ci; --cj; }
-							else if (st == 1) { st = u_open ? 2 : 1; op = 2; --cj; }
-							else if (HASJ) { st = j_open ? 2 : 0; op = 3; --cj; }       /* jump state :579-583 */
-							else { ok = false; break; }
+							const int inL = st == 3, inM = st == 2;
+							const int op = inL ? 1 : inM ? 0 : 2;
+							st = inL ? ((nb & 4u) ? 3 : 2) : inM ? (int)(nb & 3u) : (u_open ? 2 : 1);
+							ci -= inL | inM; cj -= inL ^ 1;
 							ops[cnt++] = (uint8_t)op;
 						}
 						if constexpr (MODE == K_GLOBAL) {                     /* padding loops :398-407 */

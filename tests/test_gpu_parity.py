@@ -167,7 +167,35 @@ def _rescore(ops, s1, s2, ei, ej, m, u, o, e, mode):
     return sc, i, j
 
 
-def test_full_size_c2_batch_properties(al):
+def _rescore_np(ops, s1, s2, ei, ej, m, u, o, e, g, mode):
+    """The same check for every mode, vectorised: the score the ops (END -> START) imply from the end cell, and where the
+    walk ends.  Gap runs cost o + e (k - 1) (overlap: o per op; a JUMP run: g once), the padding run with which a global
+    alignment reaches the origin along a border costs o + e k (alignment.h:429-441 against :456,460)."""
+    a = np.frombuffer(ops, dtype=np.uint8).astype(np.int64)
+    if a.size == 0:
+        return 0, ei, ej
+    b1, b2 = np.frombuffer(s1, dtype=np.uint8), np.frombuffer(s2, dtype=np.uint8)
+    di, dj = (a <= 1).astype(np.int64), (a != 1).astype(np.int64)
+    i, j = ei - np.cumsum(di), ej - np.cumsum(dj)           # the cell each op leaves the walk in
+    assert i.min() >= 0 and j.min() >= 0
+    mid = a == 0
+    sc = int(np.where(b1[i[mid]] == b2[j[mid]], m, u).sum())
+    start = np.ones(a.size, dtype=bool)
+    start[1:] = a[1:] != a[:-1]                             # first op of a run
+    if mode == "overlap":
+        sc += o * int((~mid).sum())
+    else:
+        gap = (a == 1) | (a == 2)
+        sc += o * int((gap & start).sum()) + e * int((gap & ~start).sum()) + g * int(((a == 3) & start).sum())
+        if mode == "global":
+            # ops behind the first arrival on a border are the padding run: one more e than an interior gap of its length
+            on_border = np.flatnonzero((i == 0) | (j == 0))
+            if on_border.size and on_border[0] + 1 < a.size:
+                sc += e
+    return sc, int(i[-1]), int(j[-1])
+
+
+def test_full_size_c2_batch_properties(al):def test_full_size_c2_batch_properties(al):
     """BASELINE configs[1] at full size (100k x 150x150 local): size-independent properties on every pair
     -- the ops string re-scores to the reported score, starts inside the matrix, ends in a HOME cell --
     and bit-exact equality with the oracle on a seeded sample."""
@@ -399,7 +427,7 @@ def test_baseline_shapes_at_scale(al, cfg):
     half of the pairs unrelated, half related (long tracebacks with gaps)."""
     from aligntools.c_amd.synth import synth_pairs_blob, mutate_pairs
     mode, l1, l2, n, sc, uj, sites, nsample = {
-        "C3": ("global", 1024, 1024, 4000, (1, -1, -4, -1, -10), False, [], 12),
+        "C3": ("global", 1024, 1024, 10000, (1, -1, -4, -1, -10), False, [], 12),      # the config's own 10 000 pairs
         "C4": ("fit", 150, 500, 40000, (2, -2, -5, -1, -10), True, [100, 200, 300, 400], 150),
         "C5": ("overlap", 1000, 1000, 3000, (1, -2, -5, -1, -10), False, [], 12),
     }[cfg]
@@ -421,6 +449,15 @@ def test_baseline_shapes_at_scale(al, cfg):
         r = O.align(O.MODE_NAMES[mode], pairs[k][0], pairs[k][1], *sc, uj, sites)
         assert (int(res["score"][k]), int(res["end_i"][k]), int(res["end_j"][k]), int(res["state"][k]), res["ops"][k]) == \
                (r["score"], r["end_i"], r["end_j"], r["state"], r["ops"]), (cfg, k)
+    # size-independent properties of EVERY pair: the ops re-score to the reported score, start inside the matrix at the
+    # mode's end cell and end where the mode's traceback must (global: the origin; fit: row 0; overlap: column 0)
+    m_, u_, o_, e_, g_ = sc
+    for k in range(n):
+        ei, ej = int(res["end_i"][k]), int(res["end_j"][k])
+        assert ei == l1 and (ej == l2 if mode == "global" else 0 <= ej < l2), (cfg, k, ei, ej)
+        got, i0, j0 = _rescore_np(res["ops"][k], pairs[k][0], pairs[k][1], ei, ej, m_, u_, o_, e_, g_, mode)
+        assert got == int(res["score"][k]), (cfg, k, got, int(res["score"][k]))
+        assert (i0, j0) == (0, 0) if mode == "global" else (i0 == 0 if mode == "fit" else j0 == 0), (cfg, k, i0, j0)
 
 
 def test_device_entry_refuses_broken_uniform_promise(al):

@@ -195,7 +195,7 @@ def _rescore_np(ops, s1, s2, ei, ej, m, u, o, e, g, mode):
     return sc, int(i[-1]), int(j[-1])
 
 
-def test_full_size_c2_batch_properties(al):def test_full_size_c2_batch_properties(al):
+def test_full_size_c2_batch_properties(al):
     """BASELINE configs[1] at full size (100k x 150x150 local): size-independent properties on every pair
     -- the ops string re-scores to the reported score, starts inside the matrix, ends in a HOME cell --
     and bit-exact equality with the oracle on a seeded sample."""

@@ -435,6 +435,28 @@ __global__ __launch_bounds__(64, AT_WAVES16(G, K)) void at_sweep16(const Sweep16
 					if (active) {
 						uint32_t gopen = neg2;
 						if constexpr (HASJ) gopen = ((sm >> k) & 1u) ? gmo2 : neg2;
+						if constexpr (ISFIT) {
+							/* end-cell scan of row l1, columns 0..l2-1 (:676-690), one column behind the sweep;
+							 * every lane scans its own row rl, only the owner of row l1 is read at the end.  (rl is wave-uniform, but a
+							 * scalar branch per row instead of the two select chains measured 3 % slower with pointers, 8 % without:
+							 * it cuts the unrolled step into 19 basic blocks.) */
+							if (laststrip) {
+								const uint32_t jpk = pk2(jm1);
+								uint32_t vM = psub(pick<K>(Mo_l, rl), o2);
+								uint32_t vL = pick<K>(L_l, rl);
+								if constexpr (RAG) {
+									/* an alignment's scan ends at its own column l2 - 1 */
+									const uint32_t cm = (((uint32_t)((jm1 - l2A) >> 31)) & 0xffffu) | (((uint32_t)((jm1 - l2B) >> 31)) << 16);
+									vM = vbfi(cm, vM, neg2); vL = vbfi(cm, vL, neg2);
+								}
+								uint32_t dM = psub(bestM, vM);
+								asm("" : "+v"(dM));
+								bestMj = vbfi(pneg(dM), jpk, bestMj); bestM = pmax(bestM, vM);
+								uint32_t dL = psub(bestL, vL);
+								asm("" : "+v"(dL));
+								bestLj = vbfi(pneg(dL), jpk, bestLj); bestL = pmax(bestL, vL);
+							}
+						}
 						/* step k's byte of each window against each of my query bases */
 						const uint32_t selw = __builtin_amdgcn_perm(wB[hw], wA[hw], SELK);   /* [b, b, a, a] */
 						uint32_t diag = Ad, lraw = Bup, up = 0, cmax[NCH];
@@ -446,29 +468,6 @@ __global__ __launch_bounds__(64, AT_WAVES16(G, K)) void at_sweep16(const Sweep16
 						}
 #pragma unroll
 						for (int r = 0; r < K; ++r) {
-							if constexpr (ISFIT) {
-								/* end-cell scan of row l1, columns 0..l2-1 (:676-690), one column behind the sweep: the row's values
-								 * of the previous step are still in place.  Every lane scans its row rl, only the owner of row l1 is
-								 * read at the end.  rl is wave-uniform: a scalar branch per row instead of two select chains over
-								 * all rows per step (36 of a step's 450 vector instructions with 19 rows per lane). */
-								if (laststrip && r == rl) {
-									asm volatile("" ::: "memory");      /* (keeps the branch a branch) */
-									const uint32_t jpk = pk2(jm1);
-									uint32_t vM = psub(Mo_l[r], o2);
-									uint32_t vL = L_l[r];
-									if constexpr (RAG) {
-										/* an alignment's scan ends at its own column l2 - 1 */
-										const uint32_t cm = (((uint32_t)((jm1 - l2A) >> 31)) & 0xffffu) | (((uint32_t)((jm1 - l2B) >> 31)) << 16);
-										vM = vbfi(cm, vM, neg2); vL = vbfi(cm, vL, neg2);
-									}
-									uint32_t dM = psub(bestM, vM);
-									asm("" : "+v"(dM));
-									bestMj = vbfi(pneg(dM), jpk, bestMj); bestM = pmax(bestM, vM);
-									uint32_t dL = psub(bestL, vL);
-									asm("" : "+v"(dL));
-									bestLj = vbfi(pneg(dL), jpk, bestLj); bestL = pmax(bestL, vL);
-								}
-							}
 							/* x = s2 byte ^ query byte (0 = match): selector {xB+4, xB, xA+4, xA} -> the two 16-bit scores */
 							uint32_t S;
 							if constexpr (BITS == 2) {

@@ -312,7 +312,7 @@ struct Layout16 {
  * lane-steps inside a 150 x 150 matrix, the per-step overhead spread over 19 rows), up to 208 bases as 4 groups of 16
  * lanes (8 alignments per wave, 85 %; one group of 64 lanes: 59 %), 209..416 bases as 2 groups of 32 lanes, everything
  * else as one group of 64 lanes.  AT_GROUP = 16 / 64 caps the choice (A/B runs); ragged frames name their group width themselves. */
-static Layout16 layout16_for(bool tb, bool hasj, int l1, int l2, int ts, int force_g = 0)   /* force_g: 8 / 16 = ragged frames on that group width */
+static Layout16 layout16_for(bool tb, bool hasj, int l1, int l2, int ts, int force_g = 0, bool overlap = false)   /* force_g: 8 / 16 = ragged frames on that group width */
 {
 	Layout16 L;
 	const long long g_forced = env_ll("AT_GROUP", 0);
@@ -321,6 +321,8 @@ static Layout16 layout16_for(bool tb, bool hasj, int l1, int l2, int ts, int for
 	/* scores only, scores x4: 16 rows per lane (strips of 1 024 rows) once that is fewer lane-steps than strips of 256 --
 	 * per step a lane does 16 x 11 + 25 instructions instead of 4 x 11 + 25 */
 	if (!tb && ts == 2 && !getenv("AT_ROWS_PER_LANE") && ((l1 + 1023) / 1024) * (16 * 11 + 25) < ((l1 + 255) / 256) * (4 * 11 + 25)) L.k = 16;
+	/* overlap (one state: few registers even with pointers): 4 or 16 rows per lane, whichever needs fewer instructions */
+	if (overlap) L.k = env_ll("AT_ROWS_PER_LANE", 0) == 4 ? 4 : ((l1 + 1023) / 1024) * (16 * 9 + 45) < ((l1 + 255) / 256) * (4 * 9 + 30) ? 16 : 4;
 	if (force_g != 16 && (force_g == 8 || g_forced == 0 || g_forced == 8) && ts == 4 && l1 <= 152) {
 		L.g = 8;
 		L.k = l1 <= 40 ? 5 : l1 <= 56 ? 7 : l1 <= 80 ? 10 : l1 <= 104 ? 13 : l1 <= 128 ? 16 : 19;
@@ -361,6 +363,16 @@ static bool packed_ok(const at_handle *h, int mode, int bits, int l1, int l2, in
 	const long long scale = 1LL << ts;
 	if (getenv("AT_NO_PACKED") && atoi(getenv("AT_NO_PACKED"))) return false;
 	if ((bits != 2 && bits != 8) || l1 < 1 || l2 < 1) return false;   /* 2-bit codes: score LUT; bytes: compare */
+	if (mode == AT_MODE_OVERLAP) {
+		/* one state, linear gap (alignment.h:926-964; -e unused): scores x4 with 2-bit tags only.  A cell's value is at least
+		 * that of the path along its row from column 0 (where M = 0): -|o| * j; at most m * min(l1, l2) */
+		if (ts != 2 || h->m < 0 || h->u > 0 || h->o > 0) return false;
+		const long long lo = std::llabs((long long)h->o) * std::max(l1, l2) + std::llabs((long long)h->u) + 16;
+		const long long hi = (long long)h->m * std::min(l1, l2), slack = std::llabs((long long)h->o) + std::llabs((long long)h->u) + 3;
+		if (scale * (lo + hi + slack) >= 32768) return false;
+		*thresh16 = (int)(-32768 + scale * (hi + slack));
+		return true;
+	}
 	if (!(mode == AT_MODE_GLOBAL || mode == AT_MODE_LOCAL || mode == AT_MODE_FIT)) return false;
 	if (h->m < 0 || h->u > 0 || h->o > 0 || h->e > 0) return false;
 	const bool hasj = mode == AT_MODE_FIT && h->use_jump;
@@ -667,12 +679,14 @@ static int align_device(at_handle *h, int mode, int64_t npairs,
 	if ((uniform_shape || rag) && ap_n == 0) {
 		if (packed_ok(h, mode, bits, max_len1, max_len2, 4, &thresh16)) ts = 4;
 		else if (!rag && packed_ok(h, mode, bits, max_len1, max_len2, 2, &thresh16)) ts = 2;
+		/* overlap: the packed kernel exists with pointers only (scores alone: the int32 kernel's 3 instructions per cell win) */
+		if (kmode == at::K_OVERLAP && (!tb || getenv("AT_NO_PACKED_OVERLAP"))) ts = 0;
 	}
 	if (rag && (!ts || kmode > at::K_FITJ || max_len1 > (rag == 8 ? 152 : 208) || !d_order))
 		return fail(h, AT_ERR_ARG, "ragged packed launch outside its domain");   /* the host entry checks before it asks */
 	Layout16 P;
 	if (ts) {
-		P = layout16_for(tb, kmode == at::K_FITJ, max_len1, max_len2, ts, rag);
+		P = layout16_for(tb, kmode == at::K_FITJ, max_len1, max_len2, ts, rag, kmode == at::K_OVERLAP);
 		/* A 64-lane packed wave carries 2 alignments where an int32 wave carries 1: fewer, longer work items.  A batch
 		 * that cannot give every resident wave one of them stays on the int32 kernel.  (10k x 1024^2 = 1.6 rounds: 1.96
 		 * packed vs 2.00 TCUPS int32 for a lone launch, 2.70 vs 2.13 with launches in flight; 61k pairs: 2.70 vs 2.19.) */

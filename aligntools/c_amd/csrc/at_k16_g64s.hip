@@ -22,8 +22,17 @@ static at_sweep16_fn p2(int k, int store, bool tb)
 	default: return p3<MODE, 4>(store, tb);
 	}
 }
+/* overlap, packed: with pointers only, 4 or 16 rows per lane */
+template <int K>
+static at_sweep16_fn ov3(int store)
+{
+	if (store == 0) return at::at_sweep16<at::K_OVERLAP, 64, K, 2, true, true, true, false, AT_BITS16>;
+	if (store == 1) return at::at_sweep16<at::K_OVERLAP, 64, K, 2, true, false, true, false, AT_BITS16>;
+	return at::at_sweep16<at::K_OVERLAP, 64, K, 2, false, false, true, false, AT_BITS16>;
+}
 at_sweep16_fn AT_NAME(at_pick16_g64_ts2)(int kmode, int k, int store, bool tb)
 {
+	if (kmode == at::K_OVERLAP) return !tb ? nullptr : k == 16 ? ov3<16>(store) : k == 4 ? ov3<4>(store) : nullptr;
 	switch (kmode) {
 	case at::K_GLOBAL: return p2<at::K_GLOBAL>(k, store, tb);
 	case at::K_LOCAL: return p2<at::K_LOCAL>(k, store, tb);

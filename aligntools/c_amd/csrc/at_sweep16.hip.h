@@ -189,9 +189,17 @@ __global__ __launch_bounds__(64, AT_WAVES16(G, K)) void at_sweep16(const Sweep16
 {
 	static_assert(BITS == 2 || BITS == 8, "sequence words: 16 two-bit codes or 4 bytes");
 	static_assert(!RAG || G <= 16, "ragged frames: one strip");
-	static_assert(MODE == K_GLOBAL || MODE == K_LOCAL || MODE == K_FIT || MODE == K_FITJ, "packed path: the affine modes");
+	static_assert(MODE == K_GLOBAL || MODE == K_LOCAL || MODE == K_FIT || MODE == K_FITJ || MODE == K_OVERLAP, "packed path: the affine modes, overlap");
+	/* overlap (align_overlap, alignment.h:926-964): ONE state with a linear gap, M = max5(M(i,j-1) + o, M(i-1,j-1) + s,
+	 * M(i-1,j) + o), first wins in that order -> tags LEFT 3 / DIAGONAL 2 / RIGHT 1 on the three candidates (the diagonal
+	 * one through the score LUT), the winner's tag is the cell's pointer.  Xl holds the row's clean M of the previous
+	 * column (left neighbour, and diagonal input of the row below); 9.25 instructions per row-step with pointers.  Only
+	 * built with pointers: without them the int32 kernel's three instructions per cell (SDWA add, v_max3_i32, add) win. */
+	constexpr bool OVL = MODE == K_OVERLAP;
+	static_assert(!OVL || (TB && TS == 2 && !RAG), "packed overlap: scores x4 with 2-bit tags, tracebacks, uniform batches");
 	constexpr bool HASJ = MODE == K_FITJ;
 	constexpr bool ISFIT = MODE == K_FIT || MODE == K_FITJ;
+	constexpr bool ENDSCAN = ISFIT || MODE == K_OVERLAP;   /* the end cell is the best of row l1, columns 0 .. l2 - 1 */
 	static_assert(TS == 4 || TS == 2, "scores x16 or x4");
 	constexpr int TMASK = (1 << TS) - 1;      /* tag bits of a score */
 	/* local arg-max: the key of a cell carries its row-in-lane in the tag bits, so one running maximum covers TMASK + 1
@@ -224,8 +232,11 @@ __global__ __launch_bounds__(64, AT_WAVES16(G, K)) void at_sweep16(const Sweep16
 	const int o16 = a.o16, e16 = a.e16;
 	uint32_t o2 = pk2(a.o16), e2 = pk2(a.e16);
 	/* byte LUT for v_perm: pool bytes 0..3 = low bytes of {m,u,u,u}, 4..7 = high bytes */
-	uint32_t lut_lo = ((uint32_t)a.m16 & 0xffu) | (((uint32_t)a.u16 & 0xffu) * 0x01010100u);
-	uint32_t lut_hi = (((uint32_t)a.m16 >> 8) & 0xffu) | ((((uint32_t)a.u16 >> 8) & 0xffu) * 0x01010100u);
+	const int mS = OVL ? a.m16 | 2 : a.m16, uS = OVL ? a.u16 | 2 : a.u16;   /* overlap: the diagonal candidate's tag rides on the score */
+	uint32_t lut_lo = ((uint32_t)mS & 0xffu) | (((uint32_t)uS & 0xffu) * 0x01010100u);
+	uint32_t lut_hi = (((uint32_t)mS >> 8) & 0xffu) | ((((uint32_t)uS >> 8) & 0xffu) * 0x01010100u);
+	uint32_t oL2 = pk2(a.o16 | 3), oR2 = pk2(a.o16 | 1);                    /* overlap: gap + LEFT / RIGHT tag (o16 is a multiple of 4) */
+	asm volatile("" : "+v"(oL2), "+v"(oR2));
 	/* constants live in VGPRs: VOP3 encodings take no 32-bit literals, and a literal would split and_or into two ops */
 	uint32_t cClean = (uint32_t)(0xffff & ~TMASK) * 0x00010001u, cTagM = (uint32_t)TGM * 0x00010001u;
 	uint32_t cTagL = (uint32_t)TGL * 0x00010001u, cTagU = (uint32_t)TGU * 0x00010001u;
@@ -234,7 +245,7 @@ __global__ __launch_bounds__(64, AT_WAVES16(G, K)) void at_sweep16(const Sweep16
 	 * the left state holds M + o, so the opening candidate is (M + o) + (g - o), or -inf where opening is barred */
 	uint32_t gmo2 = pk2(a.g16 - a.o16), neg2 = 0x80008000u;
 	asm volatile("" : "+v"(gmo2), "+v"(neg2));
-	uint32_t c1 = 0x00010001u, umm2 = pk2(a.u16 - a.m16), m2 = pk2(a.m16);   /* 8-bit alphabets: compare instead of LUT */
+	uint32_t c1 = 0x00010001u, umm2 = pk2(a.u16 - a.m16), m2 = pk2(mS);       /* 8-bit alphabets: compare instead of LUT */
 	asm volatile("" : "+v"(c1), "+v"(umm2), "+v"(m2));
 	asm volatile("" : "+v"(o2), "+v"(e2), "+v"(lut_lo), "+v"(lut_hi));
 	asm volatile("" : "+v"(cClean), "+v"(cTagM), "+v"(cTagL), "+v"(cTagU), "+v"(cM3), "+v"(cM7), "+v"(cNib), "+v"(cF0), "+v"(cF000));
@@ -327,8 +338,9 @@ __global__ __launch_bounds__(64, AT_WAVES16(G, K)) void at_sweep16(const Sweep16
 		for (int j = lane; j <= l2; j += 64) {
 			int L, M, U;
 			border16<MODE>(0, j, o16, e16, L, M, U);
-			const int x = imax3(L | TGL, M | TGM, U | TGU);
+			int x = imax3(L | TGL, M | TGM, U | TGU);
 			const int ld = imax(sat16((L | TGL) + e16), sat16((M | TGM) + o16));
+			if constexpr (OVL) x = j == 0 ? 0 : kNeg16;        /* M(0,j) = -inf, then M(i,0) = 0 for all i (:937-938) */
 			mem.st2(a.off_bound + 2 * j, pk2(x), pk2(ld));
 		}
 		mem.sync();
@@ -369,6 +381,7 @@ __global__ __launch_bounds__(64, AT_WAVES16(G, K)) void at_sweep16(const Sweep16
 				L_l[r] = pk2(L | TGL);
 				J_l[r] = neg2;                    /* J is -inf on both borders (:616, :622) */
 				Xl[0][r] = pk2(imax3(L | TGL, M | TGM, U | TGU));
+				if constexpr (OVL) Xl[0][r] = 0;  /* M(i,0) = 0 */
 				Xl[1][r] = Xl[0][r];
 			}
 			uint32_t A_prev = Xl[0][K - 1], B_prev = 0, Ad;
@@ -377,6 +390,7 @@ __global__ __launch_bounds__(64, AT_WAVES16(G, K)) void at_sweep16(const Sweep16
 				border16<MODE>(base, 0, o16, e16, L, M, U);
 				L = sat16(L);
 				Ad = pk2(imax3(L | TGL, M | TGM, U | TGU));
+				if constexpr (OVL) Ad = 0;
 			}
 			uint32_t best[NCH], bt[NCH];           /* local: per-lane (key, step) of this strip, per chain of rows */
 #pragma unroll
@@ -435,6 +449,16 @@ __global__ __launch_bounds__(64, AT_WAVES16(G, K)) void at_sweep16(const Sweep16
 					if (active) {
 						uint32_t gopen = neg2;
 						if constexpr (HASJ) gopen = ((sm >> k) & 1u) ? gmo2 : neg2;
+						if constexpr (OVL) {
+							/* end-cell scan of row l1, columns 0..l2-1 (:951-959), one column behind the sweep */
+							if (laststrip) {
+								const uint32_t jpk = pk2(jm1);
+								const uint32_t vM = pick<K>(Xl[k & 1], rl);
+								uint32_t dM = psub(bestM, vM);
+								asm("" : "+v"(dM));
+								bestMj = vbfi(pneg(dM), jpk, bestMj); bestM = pmax(bestM, vM);
+							}
+						}
 						if constexpr (ISFIT) {
 							/* end-cell scan of row l1, columns 0..l2-1 (:676-690), one column behind the sweep;
 							 * every lane scans its own row rl, only the owner of row l1 is read at the end.  (rl is wave-uniform, but a
@@ -466,6 +490,7 @@ __global__ __launch_bounds__(64, AT_WAVES16(G, K)) void at_sweep16(const Sweep16
 							 * lane that owns row l1 keeps the cell's three states when its column comes by */
 							if (lg == lastlane) capmask = (jm1 + 1 == l2A ? 0xffffu : 0u) | (jm1 + 1 == l2B ? 0xffff0000u : 0u);
 						}
+						uint32_t upv = Aup;                         /* overlap: M of the row above in this column */
 #pragma unroll
 						for (int r = 0; r < K; ++r) {
 							/* x = s2 byte ^ query byte (0 = match): selector {xB+4, xB, xA+4, xA} -> the two 16-bit scores */
@@ -476,6 +501,21 @@ __global__ __launch_bounds__(64, AT_WAVES16(G, K)) void at_sweep16(const Sweep16
 								/* bytes: x = {b^qB, b^qB, a^qA, a^qA}; per 16-bit half 0 = match.  z = min(x, 1), S = m + z * (u - m) */
 								const uint32_t z = pminu(selw ^ qsel[r], c1);
 								S = pmad(z, umm2, m2);
+							}
+							if constexpr (OVL) {
+								const uint32_t left = Xl[k & 1][r];
+								const uint32_t x = pmax(pmax(padd(left, oL2), padd(diag, S)), padd(upv, oR2));
+								const uint32_t Mcl = x & cClean;
+								constexpr int sw = k % SPW;         /* pointer word: see the affine modes below */
+								if constexpr (sw == 0) acc[r] = x;
+								else if constexpr (sw == 1) acc[r] = __builtin_amdgcn_perm(x, acc[r], 0x06020400u);
+								else if constexpr (sw == 2) acc[r] = vbfi(cF0, pshln<4>(x), acc[r]);
+								else acc[r] = vbfi(cF000, pshln<12>(x), acc[r]);
+								diag = left;
+								upv = Mcl;
+								up = Mcl;
+								Xl[(k & 1) ^ 1][r] = Mcl;
+								continue;
 							}
 							uint32_t Mraw = padd(diag, S);
 							if constexpr (MODE == K_LOCAL) Mraw = pmax(Mraw, 0u);
@@ -646,6 +686,12 @@ __global__ __launch_bounds__(64, AT_WAVES16(G, K)) void at_sweep16(const Sweep16
 				}
 				const int x = TB ? imax3(eL, eM, eU) : imax3(eL | OTGL, eM | OTGM, eU | OTGU);   /* max5(L,M,U) first-wins :466 */
 				sc16 = x; st = x & 3; ci = il1;
+			} else if constexpr (OVL) {
+				const int own = glane + lastlane;
+				sc16 = half((uint32_t)__builtin_amdgcn_readlane((int)bestM, own), h);   /* >= 0: column 0 holds 0 (:951-959) */
+				cj = half((uint32_t)__builtin_amdgcn_readlane((int)bestMj, own), h);
+				ci = il1; st = 2;
+				ok = sc16 > a.thresh16;
 			} else {
 				const int own = glane + lastlane;
 				const int bM = half((uint32_t)__builtin_amdgcn_readlane((int)bestM, own), h);
@@ -674,7 +720,22 @@ __global__ __launch_bounds__(64, AT_WAVES16(G, K)) void at_sweep16(const Sweep16
 					const int glane = g * G;
 					int guard = l1 + l2 + 2;
 					if (AT_WALK_PRIO) __builtin_amdgcn_s_setprio(AT_WALK_PRIO);
-					if (ok && ISFIT) {
+					if (ok && OVL) {
+						/* overlap (trace_back_overlap :896-922): the cell's pointer is the move -- LEFT 3: ('-', s2[--j]),
+						 * DIAGONAL 2: both, RIGHT 1: (s1[--i], '-') -- until column 0 */
+						while (cj > 0 && --guard >= 0) {
+							if (ci <= 0) { ok = false; break; }               /* (row 0 is -inf beyond column 0: no path leads there) */
+							const int ss = G == 64 ? (ci - 1) / RS : 0, li = G == 64 ? (ci - 1) % RS : ci - 1;
+							const int ln = li / K, r = li % K;
+							const int t = (cj - 1) + ln;
+							const uint32_t w = pm.ld(a.off_ptr + (G == 64 ? __mul24(ss, wps * NL) : 0) + pidx<PTRLDS, K>(t / SPW, r, glane + ln, NL));
+							const uint32_t nb = (w >> (16 * h + cell_shift<PB>(t % SPW))) & 3u;
+							if (nb == 0) { ok = false; break; }
+							ops[cnt++] = (uint8_t)(nb == 3 ? 2 : nb == 2 ? 0 : 1);
+							ci -= nb != 3; cj -= nb != 1;
+						}
+						if (guard < 0) ok = false;
+					} else if (ok && ISFIT) {
 						/* fit: the walk crosses the whole read, and with the jump state a run of JUMP ops crosses hundreds of
 						 * columns (C4: 380 ops per pair on average), every op a dependent load from HBM.  Runs are predictable:
 						 * while the state does not change the walk keeps its direction (LOW up, MID diagonal, UPP / JUMP left).

@@ -377,6 +377,52 @@ def test_score_only_long_pairs_sixteen_rows_per_lane(al):
     assert seen16
 
 
+def test_packed_overlap_with_tracebacks(al):
+    """Uniform overlap batches with tracebacks run on the packed kernel (scores x4, LEFT / DIAGONAL / RIGHT tags): 4 and 16
+    rows per lane, one and several strips, true overlaps (suffix of s1 = prefix of s2, with errors), unrelated pairs and empty
+    results, 2-bit and byte alphabets, against the oracle; scores-only batches and scorings outside the 16-bit range stay on
+    the int32 kernel."""
+    rng = random.Random(926)
+    for l1, l2, alpha in ((40, 60, "ACGT"), (150, 150, "ACGT"), (256, 200, "ACGTN"), (300, 300, "ACGT"), (1000, 1000, "ACGT"), (1100, 700, "ACGT")):
+        dna = lambda n: "".join(rng.choice(alpha) for _ in range(n))
+        pairs = []
+        for k in range(9):
+            a = dna(l1)
+            if k % 3 == 0:
+                b = dna(l2)
+            else:
+                ov = rng.randint(5, min(l1, l2) - 2)
+                t = list(a[l1 - ov:])
+                for _ in range(ov // 20):
+                    q = rng.randrange(len(t))
+                    x = rng.random()
+                    if x < 0.5:
+                        t[q] = rng.choice(alpha)
+                    elif x < 0.75 and len(t) > 2:
+                        del t[q]
+                    else:
+                        t.insert(q, rng.choice(alpha))
+                b = ("".join(t) + dna(l2))[:l2]
+            pairs.append((a, b))
+        for sc in ((1, -2, -5, -1), (2, -1, -1, -1), (1, -1, 0, 0)):
+            al.set_scoring(*sc)
+            res = al.align_batch("overlap", pairs, render=False)
+            assert "packed16 x4" in al.last_config, (l1, l2, sc, al.last_config)
+            for k, (a, b) in enumerate(pairs):
+                r = O.align(O.OVERLAP, a, b, *sc)
+                assert (int(res["score"][k]), int(res["end_i"][k]), int(res["end_j"][k]), int(res["state"][k]), res["ops"][k]) == \
+                       (r["score"], r["end_i"], r["end_j"], r["state"], r["ops"]), (l1, l2, sc, k)
+            res = al.align_batch("overlap", pairs, traceback=False)
+            assert "int32" in al.last_config
+    al.set_scoring(3, -4, -9, -1)
+    pairs = [("".join(rng.choice("ACGT") for _ in range(1000)),) * 2 for _ in range(4)]
+    res = al.align_batch("overlap", pairs, render=False)           # 4 * (9 * 1000 + 3 * 1000) > 2^15: int32
+    assert "int32" in al.last_config
+    for k, (a, b) in enumerate(pairs):
+        r = O.align(O.OVERLAP, a, b, 3, -4, -9, -1)
+        assert (int(res["score"][k]), res["ops"][k]) == (r["score"], r["ops"])
+
+
 def test_deep_lane_kernels_overlap_scores_and_edit(al):
     """Overlap without tracebacks and edit run with 8 or 16 rows per lane once the first sequence is longer than 256:
     one strip (257..1024 rows), several strips (> 1024), ragged batches, row l1 anywhere inside its lane, both alphabets."""

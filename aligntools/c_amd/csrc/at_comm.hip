@@ -91,7 +91,7 @@ int dev_buf(at_handle *h, Comm *c, size_t need)
 /* every rank contributes `n` bytes (the same n everywhere); `all` receives world * n bytes in rank order */
 int allgather_fixed(at_handle *h, Comm *c, const void *mine, size_t n, void *all)
 {
-	if (c->world == 1) { memcpy(all, mine, n); return AT_OK; }
+	if (c->world == 1 && !c->comm) { memcpy(all, mine, n); return AT_OK; }
 	if (c->files) {
 		const long q = c->seq++;
 		char name[64];
@@ -129,7 +129,9 @@ extern "C" int at_comm_init(at_handle *h, int rank, int world, const char *dir)
 	const char *mode = getenv("AT_COMM");
 	c->files = mode && strcmp(mode, "files") == 0;
 	*at_comm_slot(h) = c;
-	if (c->files || world == 1) return AT_OK;
+	/* (a world of one needs no collective; AT_COMM_FORCE_RCCL=1 builds the communicator anyway, so that the RCCL branch --
+	 * dlopen, ncclCommInitRank, ncclBroadcast, ncclAllGather -- can be exercised on a one-GPU box) */
+	if (c->files || (world == 1 && !getenv("AT_COMM_FORCE_RCCL"))) return AT_OK;
 	if (hipSetDevice(at_handle_device(h)) != hipSuccess || hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess)
 		return at_comm_fail(h, AT_ERR_NODEVICE, "at_comm_init: no stream on this rank's device");
 	c->lib = dlopen("librccl.so.1", RTLD_NOW | RTLD_LOCAL);
@@ -168,7 +170,7 @@ extern "C" int at_comm_broadcast_scoring(at_handle *h)
 	const int *sites = nullptr;
 	at_get_scoring(h, v, &sites);                 /* v[0..5] = m,u,o,e,j,use_jump, v[6] = nsites */
 	std::vector<int> st(sites, sites + v[6]);
-	if (c->world > 1) {
+	if (c->world > 1 || c->comm) {
 		if (c->files) {
 			const long q = c->seq++;
 			char name[64];

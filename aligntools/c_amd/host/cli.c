@@ -192,7 +192,8 @@ static int batch_worker(int cmd, opt_t *opt, const batch_flags *bf, const char *
 	     : cmd == C_OVERLAP ? AT_MODE_OVERLAP : AT_MODE_EDIT;
 	h = at_host_handle();
 	rc = at_set_scoring(h, opt->m, opt->u, opt->o, opt->e, opt->j, opt->s == AT_TRUE, opt->sites.pos, (int)opt->sites.size);
-	if (rc == AT_OK && world > 1) {
+	const int comm = world > 1 || getenv("AT_COMM_FORCE_RCCL") != NULL;   /* (the latter: the RCCL calls at world size 1, for tests) */
+	if (rc == AT_OK && comm) {
 		rc = at_comm_init(h, rank, world, comm_dir);
 		if (rc == AT_OK) rc = at_comm_broadcast_scoring(h);      /* rank 0's options are everybody's */
 	}
@@ -205,7 +206,7 @@ static int batch_worker(int cmd, opt_t *opt, const batch_flags *bf, const char *
 			rc = at_align_batch_strings(h, mode, n, blob, off1, l1, off2, l2, score, ei, ej, st, r1, r2, slot, nops);
 	}
 	if (rc != AT_OK) die("%s", at_last_error(h));
-	if (world == 1) {
+	if (!comm) {
 		int64_t a = 0, b = 0;
 		for (k = 0; k < n; ++k) {
 			if (bf->all_vs_all) tri_pair(lo + k, (int64_t)nrec, &a, &b); else { a = 2 * (lo + k); b = a + 1; }

@@ -167,6 +167,11 @@ def test_cli_batch_gpus_n_matches_one_gpu(built, tmp_path, flags):
         assert p.returncode == 0, (n, p.stderr[-2000:])
         assert p.stdout == one.stdout, (n, flags)
         assert p.stderr.decode().count("[main] CMD:") == 1      # only rank 0 signs off
+    # the RCCL branch itself (dlopen, ncclCommInitRank, ncclBroadcast, ncclAllGather) with a world of one rank on this card
+    rccl = subprocess.run(base + ["--gpus", "1", "reads.fa"], cwd=tmp_path, capture_output=True, timeout=600,
+                          env=dict(os.environ, AT_COMM_FORCE_RCCL="1", HSA_ENABLE_IPC_MODE_LEGACY="0"))
+    assert rccl.returncode == 0, rccl.stderr[-2000:]
+    assert rccl.stdout == one.stdout, flags
     # a failing rank ends the whole job with its code: fit with a read longer than its contig
     with open(tmp_path / "bad.fa", "w") as fh:
         fh.write(">a\nACGTACGTAC\n>b\nACGT\n>c\nAC\n>d\nACGT\n")

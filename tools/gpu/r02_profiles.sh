@@ -23,6 +23,10 @@ done
 for W in C2 C3 C4; do
   timeout -k 10 300 python3 bench.py --workload $W --steps 60 --no-traceback --no-cpu-baseline >> $O/workloads_bench.jsonl 2>> $O/bench.err
 done
+# A/B lines: C5 on the int32 kernel, C2 / C4 on the 16-lane groups
+AT_NO_PACKED_OVERLAP=1 timeout -k 10 300 python3 bench.py --workload C5 --steps 60 --no-cpu-baseline > $O/ab_C5_int32_bench.json 2>> $O/bench.err
+AT_GROUP=16 timeout -k 10 300 python3 bench.py --workload C2 --steps 60 --no-cpu-baseline > $O/ab_C2_group16_bench.json 2>> $O/bench.err
+AT_GROUP=16 timeout -k 10 300 python3 bench.py --workload C4 --steps 60 --no-cpu-baseline > $O/ab_C4_group16_bench.json 2>> $O/bench.err
 timeout -k 10 300 python3 bench.py --gpus 1 --steps 20 --warmup 5 > $O/c2_driver_style_bench.json 2>> $O/bench.err
 timeout -k 10 300 python3 bench.py --streams 1 --steps 60 --no-cpu-baseline > $O/c2_streams1_bench.json 2>> $O/bench.err
 # rocprofv3 kernel stats of the default command

@@ -155,7 +155,14 @@ extern "C" int at_comm_init(at_handle *h, int rank, int world, const char *dir)
 		if (!wait_for_file(idfile, d, 120.0) || d.size() != sizeof id) return at_comm_fail(h, AT_ERR_NODEVICE, "at_comm_init: rank 0 never published its RCCL id");
 		memcpy(&id, d.data(), sizeof id);
 	}
+	/* RCCL prints a version banner on stdout when a communicator comes up: the CLI's stdout is its result, so the banner
+	 * goes to stderr */
+	fflush(stdout);
+	const int saved = dup(1);
+	if (saved >= 0) (void)dup2(2, 1);
 	const int e = init(&c->comm, world, id, rank);
+	fflush(stdout);
+	if (saved >= 0) { (void)dup2(saved, 1); close(saved); }
 	if (e) return at_comm_fail(h, AT_ERR_NODEVICE, c->errstr ? c->errstr(e) : "ncclCommInitRank failed");
 	return AT_OK;
 }

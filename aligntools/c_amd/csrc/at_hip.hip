@@ -325,7 +325,7 @@ static Layout16 layout16_for(bool tb, bool hasj, int l1, int l2, int ts, int for
 	if (overlap) L.k = env_ll("AT_ROWS_PER_LANE", 0) == 4 ? 4 : ((l1 + 1023) / 1024) * (16 * 9 + 45) < ((l1 + 255) / 256) * (4 * 9 + 30) ? 16 : 4;
 	if (force_g != 16 && (force_g == 8 || g_forced == 0 || g_forced == 8) && ts == 4 && l1 <= 152) {
 		L.g = 8;
-		L.k = l1 <= 40 ? 5 : l1 <= 56 ? 7 : l1 <= 80 ? 10 : l1 <= 104 ? 13 : l1 <= 128 ? 16 : 19;
+		L.k = l1 <= 40 ? 5 : l1 <= 48 ? 6 : l1 <= 56 ? 7 : l1 <= 64 ? 8 : l1 <= 80 ? 10 : l1 <= 104 ? 13 : l1 <= 128 ? 16 : 19;
 	} else if ((force_g == 16 || g_forced != 64) && ts == 4 && l1 <= 208) {
 		L.g = 16;
 		L.k = l1 <= 64 ? 4 : l1 <= 80 ? 5 : l1 <= 96 ? 6 : l1 <= 112 ? 7 : (l1 <= 160 ? 10 : 13);
@@ -983,7 +983,7 @@ static int align_host(at_handle *h, int mode, int64_t npairs, const uint8_t *seq
 		};
 		/* global / fit: (group width, rows per lane) of a read length */
 		auto gclass = [](int l1) { return l1 <= 152 ? 8 : 16; };
-		auto kclass2 = [](int l1) { return l1 <= 40 ? 5 : l1 <= 56 ? 7 : l1 <= 80 ? 10 : l1 <= 104 ? 13 : l1 <= 128 ? 16 : l1 <= 152 ? 19 : l1 <= 160 ? 10 : 13; };
+		auto kclass2 = [](int l1) { return l1 <= 40 ? 5 : l1 <= 48 ? 6 : l1 <= 56 ? 7 : l1 <= 64 ? 8 : l1 <= 80 ? 10 : l1 <= 104 ? 13 : l1 <= 128 ? 16 : l1 <= 152 ? 19 : l1 <= 160 ? 10 : 13; };
 		if (frames && mode == AT_MODE_LOCAL) {
 			/* (class descending, l2 descending, index ascending): a counting sort -- the key space is 6 x (max2 + 1) */
 			auto kidx = [&](int l1) {   /* classes in descending order of rows per lane */

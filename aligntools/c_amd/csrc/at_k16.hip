@@ -9,6 +9,7 @@
 	at_sweep16_fn at_pick16_rag8a_b##b(int kmode, int k, int store, bool tb);      \
 	at_sweep16_fn at_pick16_rag8b_b##b(int kmode, int k, int store, bool tb);      \
 	at_sweep16_fn at_pick16_rag8c_b##b(int kmode, int k, int store, bool tb);      \
+	at_sweep16_fn at_pick16_rag8d_b##b(int kmode, int k, int store, bool tb);      \
 	at_sweep16_fn at_pick16_rag16_b##b(int kmode, int k, int store, bool tb);
 AT_DECL(2)
 AT_DECL(8)
@@ -27,6 +28,7 @@ at_sweep16_fn at_pick16(int kmode, int g, int k, int ts, int store, bool tb, int
 at_sweep16_fn at_pick16_rag(int kmode, int g, int k, int store, bool tb, int bits)
 {
 	if (g == 8) {
+		if (k == 6 || k == 8) return bits == 8 ? at_pick16_rag8d_b8(kmode, k, store, tb) : at_pick16_rag8d_b2(kmode, k, store, tb);
 		if (bits == 8) return k >= 19 ? at_pick16_rag8c_b8(kmode, k, store, tb) : k >= 13 ? at_pick16_rag8b_b8(kmode, k, store, tb) : at_pick16_rag8a_b8(kmode, k, store, tb);
 		return k >= 19 ? at_pick16_rag8c_b2(kmode, k, store, tb) : k >= 13 ? at_pick16_rag8b_b2(kmode, k, store, tb) : at_pick16_rag8a_b2(kmode, k, store, tb);
 	}

@@ -1,6 +1,6 @@
 #include "at_launch.h"
 /* packed kernels, eight groups of 8 lanes (16 alignments per wavefront) for reads of up to 152 bases: K rows per lane =
- * ceil(l1 / 8) rounded up to one of {5, 7, 10, 13, 16, 19}.  150 x 150: 150 of 152 rows and 150 of 157 steps carry cells
+ * ceil(l1 / 8) rounded up to one of {5, 6, 7, 8, 10, 13, 16, 19}.  150 x 150: 150 of 152 rows and 150 of 157 steps carry cells
  * (94 percent; four groups of 16 lanes x 10 rows: 85), and the per-step overhead is spread over 19 rows.  The pointer
  * matrix always lives in the per-wave global slots (16 alignments do not fit LDS); this unit: K in {13, 16} */
 template <int MODE, int K>

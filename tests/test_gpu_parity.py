@@ -641,7 +641,7 @@ def test_ragged_global_and_fit_batches_in_frames(al, mode):
     rng = random.Random(4471)
     uj = mode == "fitj"
     m = "fit" if uj else mode
-    for alpha, lens in (("ACGT", [1, 2, 39, 40, 41, 56, 57, 80, 81, 104, 105, 128, 129, 150, 151, 152, 153, 160, 161, 200, 208]), ("ACGTN", [30, 100, 150, 180])):
+    for alpha, lens in (("ACGT", [1, 2, 39, 40, 41, 48, 49, 56, 57, 64, 65, 80, 81, 104, 105, 128, 129, 150, 151, 152, 153, 160, 161, 200, 208]), ("ACGTN", [30, 100, 150, 180])):
         dna = lambda n: "".join(rng.choice(alpha) for _ in range(n))
         pairs = []
         for k in range(1400):
@@ -1096,7 +1096,8 @@ def test_packed_8_lane_groups(al, mode):
     rng = random.Random(808)
     uj = mode == "fitj"
     m = "fit" if uj else mode
-    for l1, l2, alpha, n in ((1, 9, "ACGT", 3), (36, 36, "ACGT", 40), (40, 120, "ACGT", 17), (41, 41, "ACGTN", 33), (56, 70, "ACGT", 16), (57, 57, "ACGT", 31),
+    for l1, l2, alpha, n in ((1, 9, "ACGT", 3), (36, 36, "ACGT", 40), (40, 120, "ACGT", 17), (41, 41, "ACGTN", 33), (48, 48, "ACGT", 20), (49, 60, "ACGT", 17), (56, 70, "ACGT", 16), (57, 57, "ACGT", 31),
+                             (64, 64, "ACGT", 33), (65, 65, "ACGTN", 18),
                              (80, 80, "ACGT", 48), (81, 150, "ACGTN", 19), (104, 104, "ACGT", 23), (105, 130, "ACGT", 32), (128, 128, "ACGT", 35),
                              (129, 500, "ACGT", 21), (150, 150, "ACGT", 50), (150, 500, "ACGT", 37), (152, 152, "ACGTN", 18), (151, 153, "ACGT", 5)):
         pairs = []

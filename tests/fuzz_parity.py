@@ -100,4 +100,5 @@ def run(cases, seed, al=None, verbose=True):
 
 
 if __name__ == "__main__":
+    os.environ.setdefault("AT_PACKED_MIN_ROUNDS", "0")   # small batches must still reach the 64-lane packed kernels
     run(int(sys.argv[1]) if len(sys.argv) > 1 else 20000, int(sys.argv[2]) if len(sys.argv) > 2 else 1)

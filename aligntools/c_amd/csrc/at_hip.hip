@@ -312,7 +312,7 @@ struct Layout16 {
  * lane-steps inside a 150 x 150 matrix, the per-step overhead spread over 19 rows), up to 208 bases as 4 groups of 16
  * lanes (8 alignments per wave, 85 %; one group of 64 lanes: 59 %), 209..416 bases as 2 groups of 32 lanes, everything
  * else as one group of 64 lanes.  AT_GROUP = 16 / 64 caps the choice (A/B runs); ragged frames name their group width themselves. */
-static Layout16 layout16_for(bool tb, bool hasj, int l1, int l2, int ts, int force_g = 0, bool overlap = false)   /* force_g: 8 / 16 = ragged frames on that group width */
+static Layout16 layout16_for(bool tb, bool hasj, int l1, int l2, int ts, int force_g = 0, bool overlap = false)   /* force_g: 8 / 16 = ragged frames on that group width; 64 = tail */
 {
 	Layout16 L;
 	const long long g_forced = env_ll("AT_GROUP", 0);
@@ -323,7 +323,9 @@ static Layout16 layout16_for(bool tb, bool hasj, int l1, int l2, int ts, int for
 	if (!tb && ts == 2 && !getenv("AT_ROWS_PER_LANE") && ((l1 + 1023) / 1024) * (16 * 11 + 25) < ((l1 + 255) / 256) * (4 * 11 + 25)) L.k = 16;
 	/* overlap (one state: few registers even with pointers): 4 or 16 rows per lane, whichever needs fewer instructions */
 	if (overlap) L.k = env_ll("AT_ROWS_PER_LANE", 0) == 4 ? 4 : ((l1 + 1023) / 1024) * (16 * 9 + 45) < ((l1 + 255) / 256) * (4 * 9 + 30) ? 16 : 4;
-	if (force_g != 16 && (force_g == 8 || g_forced == 0 || g_forced == 8) && ts == 4 && l1 <= 152) {
+	if (force_g == 64) {
+		/* the sliver of a batch behind its whole rounds (align_device): one group of 64 lanes, whatever the read length */
+	} else if (force_g != 16 && (force_g == 8 || g_forced == 0 || g_forced == 8) && ts == 4 && l1 <= 152) {
 		L.g = 8;
 		L.k = l1 <= 40 ? 5 : l1 <= 48 ? 6 : l1 <= 56 ? 7 : l1 <= 64 ? 8 : l1 <= 80 ? 10 : l1 <= 104 ? 13 : l1 <= 128 ? 16 : 19;
 	} else if ((force_g == 16 || g_forced != 64) && ts == 4 && l1 <= 208) {
@@ -525,7 +527,7 @@ static int align_device(at_handle *h, int mode, int64_t npairs,
                         int32_t *d_score, int32_t *d_end_i, int32_t *d_end_j, int32_t *d_state,
                         uint8_t *d_ops, const int64_t *d_ops_off, int32_t *d_nops, void *stream_,
                         int64_t ap_n, int64_t ap_first, const int *d_order = nullptr, int rag = 0,
-                        const int *only_if = nullptr, int only_val = 0);
+                        const int *only_if = nullptr, int only_val = 0, int tail = 0);
 
 extern "C" int at_align_batch_device(at_handle *h, int mode, int64_t npairs,
                                      const uint32_t *d_seq, int bits,
@@ -626,7 +628,7 @@ static int align_device(at_handle *h, int mode, int64_t npairs,
                         int32_t max_len1, int32_t max_len2, int uniform_shape, int want_traceback,
                         int32_t *d_score, int32_t *d_end_i, int32_t *d_end_j, int32_t *d_state,
                         uint8_t *d_ops, const int64_t *d_ops_off, int32_t *d_nops, void *stream_,
-                        int64_t ap_n, int64_t ap_first, const int *d_order, int rag, const int *only_if, int only_val)
+                        int64_t ap_n, int64_t ap_first, const int *d_order, int rag, const int *only_if, int only_val, int tail)
 {
 	if (!h) return fail(nullptr, AT_ERR_ARG, "at_align_batch_device: NULL handle");
 	if (mode < AT_MODE_GLOBAL || mode > AT_MODE_EDIT) return fail(h, AT_ERR_ARG, "unknown mode %d", mode);
@@ -686,12 +688,12 @@ static int align_device(at_handle *h, int mode, int64_t npairs,
 		return fail(h, AT_ERR_ARG, "ragged packed launch outside its domain");   /* the host entry checks before it asks */
 	Layout16 P;
 	if (ts) {
-		P = layout16_for(tb, kmode == at::K_FITJ, max_len1, max_len2, ts, rag, kmode == at::K_OVERLAP);
+		P = layout16_for(tb, kmode == at::K_FITJ, max_len1, max_len2, ts, tail ? 64 : rag, kmode == at::K_OVERLAP);
 		/* A 64-lane packed wave carries 2 alignments where an int32 wave carries 1: fewer, longer work items.  A batch
 		 * that cannot give every resident wave one of them stays on the int32 kernel.  (10k x 1024^2 = 1.6 rounds: 1.96
 		 * packed vs 2.00 TCUPS int32 for a lone launch, 2.70 vs 2.13 with launches in flight; 61k pairs: 2.70 vs 2.19.) */
 		const double min_rounds = getenv("AT_PACKED_MIN_ROUNDS") ? atof(getenv("AT_PACKED_MIN_ROUNDS")) : 1.0;
-		if (P.g == 64 && (double)((npairs + 1) / 2) < min_rounds * 12.0 * h->ncu) ts = 0;
+		if (P.g == 64 && !tail && (double)((npairs + 1) / 2) < min_rounds * 12.0 * h->ncu) ts = 0;
 		/* the packed kernels index their slot with 24-bit multiplies: a pair whose slot would not fit takes the int32 kernel */
 		if (P.words >= (1LL << 24)) { if (rag) return fail(h, AT_ERR_ARG, "ragged packed launch outside its domain (slot too large)"); ts = 0; }
 		/* no packed kernel for the storage class this shape needs (the 16- and 32-lane groups have no all-HBM variant:
@@ -726,9 +728,25 @@ static int align_device(at_handle *h, int mode, int64_t npairs,
 		snprintf(tag16, sizeof tag16, "packed16 x%d bits=%d %dx%d-lane groups (%d pairs/wave)%s", 1 << ts, bits, 64 / P.g, P.g, per_wave,
 		         rag ? " ragged frames" : "");
 		auto pick = [&](int st) { return rag ? at_pick16_rag(kmode, P.g, P.k, st, tb, bits) : at_pick16(kmode, P.g, P.k, ts, st, tb, bits); };
-		int rc = plan_launch(h, tag16, P.k, (npairs + per_wave - 1) / per_wave, P.off_ptr, P.words - P.off_ptr, &pl, stream,
+		const long long nwork = (npairs + per_wave - 1) / per_wave;
+		int rc = plan_launch(h, tag16, P.k, nwork, P.off_ptr, P.words - P.off_ptr, &pl, stream,
 		                     [&](int st) { return (const void *)pick(st); }, P.g < 64);
 		if (rc) return rc;
+		/* The grid is the resident waves, each pulling work items until none are left: a batch of 3.05 rounds (C2: 6 250 items of
+		 * 16 pairs on 2 048 waves) ends with a round in which 5 % of the waves work and the rest of the chip waits a whole item
+		 * time for them.  AT_TAIL_SPLIT=1: when such a sliver remains, the main launch takes the whole rounds and the sliver goes
+		 * to the 64-lane kernel behind it -- two alignments per wave, items an eighth as long, enough of them to fill the chip.
+		 * Off by default: it helps a caller who waits for each launch (C2 one launch at a time 2 263 -> 2 367 GCUPS, scores only
+		 * 3 867 -> 4 009) and costs one who keeps launches in flight, where the next launch fills the idle SIMDs anyway and the
+		 * second launch is pure overhead (C2 on 3 streams 2 921 -> 2 699; C4 2 058 -> 2 018).  profiles/r02/ab_tail_split.json */
+		int64_t n_tail = 0;
+		if (!tail && !rag && !only_if && P.g <= 16 && nwork > pl.grid && env_ll("AT_TAIL_SPLIT", 0)) {
+			const long long sliver = nwork % pl.grid;
+			if (sliver > 0 && sliver * 3 <= pl.grid) {
+				n_tail = npairs - (nwork - sliver) * per_wave;
+				b.npairs = npairs - n_tail;
+			}
+		}
 		b.off_ptr = pl.off_ptr; b.ws = pl.ws; b.ws_slot_words = pl.slot_words; b.queue = h->d_queue;
 		at_sweep16_fn fn16 = pick(pl.store);
 		if (!fn16 || (P.g != 64 && pl.store == 2)) return fail(h, AT_ERR_RANGE, "no packed kernel for this shape (rows/lane=%d, store=%d)", P.k, pl.store);
@@ -736,8 +754,15 @@ static int align_device(at_handle *h, int mode, int64_t npairs,
 			HIP_TRY(h, hipFuncSetAttribute((const void *)fn16, hipFuncAttributeMaxDynamicSharedMemorySize, (int)pl.dyn_lds));
 		hipLaunchKernelGGL(fn16, dim3((unsigned)pl.grid), dim3(64), pl.dyn_lds, stream, b);
 		HIP_TRY(h, hipGetLastError());
-		/* (Tried and dropped: sweeping the remainder of a batch that is not a multiple of resident-waves x 8 with a
-		 * second, finer-grained launch -- the second launch costs as much as the lone last round it replaces.) */
+		if (n_tail > 0) {
+			const int64_t nm = npairs - n_tail;
+			const std::string main_cfg = h->cfg;
+			rc = align_device(h, mode, n_tail, d_seq, bits, d_woff1 + nm, d_len1 + nm, d_woff2 + nm, d_len2 + nm, max_len1, max_len2, 1, want_traceback,
+			                  d_score + nm, d_end_i ? d_end_i + nm : nullptr, d_end_j ? d_end_j + nm : nullptr, d_state ? d_state + nm : nullptr,
+			                  d_ops, d_ops_off ? d_ops_off + nm : nullptr, d_nops ? d_nops + nm : nullptr, stream_, 0, 0, nullptr, 0, nullptr, 0, 1);
+			if (rc) return rc;
+			snprintf(h->cfg, sizeof h->cfg, "%.230s + last %lld pairs on 64-lane groups", main_cfg.c_str(), (long long)n_tail);
+		}
 		return AT_OK;
 	}
 
@@ -976,8 +1001,8 @@ static int align_host(at_handle *h, int mode, int64_t npairs, const uint8_t *seq
 		}
 		/* local: the 16-lane groups (their frames mix read lengths freely; on the 8-lane groups, whose lanes carry up to 19
 		 * rows, the same batches ran 15 % slower: 100..150 x 100..150 2.9 against 2.5 ms per 100k pairs) */
-		const int gl = 16;
-		auto kclass = [gl](int l1) {
+		constexpr int gl = 16;
+		auto kclass = [](int l1) {
 			return gl == 8 ? (l1 <= 40 ? 5 : l1 <= 56 ? 7 : l1 <= 80 ? 10 : l1 <= 104 ? 13 : l1 <= 128 ? 16 : 19)
 			               : (l1 <= 64 ? 4 : l1 <= 80 ? 5 : l1 <= 96 ? 6 : l1 <= 112 ? 7 : l1 <= 160 ? 10 : 13);
 		};

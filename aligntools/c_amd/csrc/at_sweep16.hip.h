@@ -199,7 +199,6 @@ __global__ __launch_bounds__(64, AT_WAVES16(G, K)) void at_sweep16(const Sweep16
 	static_assert(!OVL || (TB && TS == 2 && !RAG), "packed overlap: scores x4 with 2-bit tags, tracebacks, uniform batches");
 	constexpr bool HASJ = MODE == K_FITJ;
 	constexpr bool ISFIT = MODE == K_FIT || MODE == K_FITJ;
-	constexpr bool ENDSCAN = ISFIT || MODE == K_OVERLAP;   /* the end cell is the best of row l1, columns 0 .. l2 - 1 */
 	static_assert(TS == 4 || TS == 2, "scores x16 or x4");
 	constexpr int TMASK = (1 << TS) - 1;      /* tag bits of a score */
 	/* local arg-max: the key of a cell carries its row-in-lane in the tag bits, so one running maximum covers TMASK + 1

@@ -4,6 +4,7 @@
   (2) the oracle restatement on fresh seeded inputs (ops, end cell, start state).
 """
 import hashlib
+import os
 import random
 from collections import defaultdict
 
@@ -1130,6 +1131,67 @@ def test_packed_8_lane_groups(al, mode):
                        (r["score"], r["end_i"], r["end_j"], r["state"]), (mode, l1, l2, k, tb)
                 if tb:
                     assert res["ops"][k] == r["ops"], (mode, l1, l2, k)
+
+
+@pytest.mark.parametrize("mode", ["local", "global", "fit", "fitj"])
+def test_sliver_of_a_batch_on_64_lane_groups(al, mode, monkeypatch):
+    """AT_TAIL_SPLIT=1 (off by default: it pays for lone launches only): a uniform batch that fills the resident waves a whole
+    number of times plus a sliver (less than a third of a round) is split: whole rounds on the 8- or 16-lane groups, the sliver
+    on the 64-lane kernel behind them (at_hip.hip, align_device).
+    The split batch equals the unsplit one everywhere and the oracle on the sliver and on a sample of the rest."""
+    import re
+    monkeypatch.setenv("AT_HOST_CHUNKS", "1")      # the host entry would cut the batch into chunks side by side: one launch here
+    rng = random.Random(4242)
+    uj = mode == "fitj"
+    m = "fit" if uj else mode
+    sc = (2, -2, -5, -2, -9) if mode != "global" else (1, -2, -4, -1, -9)
+    sites = [5, 30, 44]
+    al.set_scoring(*sc, uj, sites)
+    for l1, l2 in ((60, 64), (170, 200)):
+        def mk():
+            a = "".join(rng.choice("ACGT") for _ in range(l1))
+            if rng.random() < 0.6:
+                t = list(a)
+                for _ in range(1 + l1 // 15):
+                    q = rng.randrange(len(t))
+                    r = rng.random()
+                    if r < 0.5:
+                        t[q] = rng.choice("ACGT")
+                    elif r < 0.75 and len(t) > 1:
+                        del t[q]
+                    else:
+                        t.insert(q, rng.choice("ACGT"))
+                b = ("".join(rng.choice("ACGT") for _ in range(rng.randint(0, 9))) + "".join(t) + "".join(rng.choice("ACGT") for _ in range(l2)))[:l2]
+            else:
+                b = "".join(rng.choice("ACGT") for _ in range(l2))
+            return a, b
+        probe = [mk() for _ in range(64)]
+        fresh = [mk() for _ in range(700)]
+        base = [mk() for _ in range(2048)]
+        for tb in (True, False):
+            al.align_batch(m, probe * 1024, traceback=tb, render=False)    # one full-size call tells the grid of this kernel on this chip
+            g = re.search(r"(\d+)x(\d+)-lane groups \((\d+) pairs/wave\).* grid=(\d+)", al.last_config)
+            assert g and int(g.group(2)) in (8, 16), al.last_config
+            per_wave, grid = int(g.group(3)), int(g.group(4))
+            n = (grid + 37) * per_wave - 3                              # one round, then 37 work items, the last one not full
+            pairs = (base * (n // 2048 + 1))[:n - 700] + fresh
+            monkeypatch.setenv("AT_TAIL_SPLIT", "0")
+            whole = al.align_batch(m, pairs, traceback=tb, render=False)
+            assert "64-lane groups" not in al.last_config
+            monkeypatch.setenv("AT_TAIL_SPLIT", "1")
+            res = al.align_batch(m, pairs, traceback=tb, render=False)
+            assert "+ last %d pairs on 64-lane groups" % (37 * per_wave - 3) in al.last_config, al.last_config
+            for key in ("score", "end_i", "end_j", "state"):
+                assert (np.asarray(res[key]) == np.asarray(whole[key])).all(), (mode, l1, key)
+            if tb:
+                assert res["ops"] == whole["ops"], (mode, l1)
+            for k in list(range(n - 700, n)) + list(range(0, n - 700, 97)):
+                x, y = pairs[k]
+                r = O.align(O.MODE_NAMES[m], x, y, *sc, uj, sites)
+                assert (int(res["score"][k]), int(res["end_i"][k]), int(res["end_j"][k]), int(res["state"][k])) == \
+                       (r["score"], r["end_i"], r["end_j"], r["state"]), (mode, l1, k, tb)
+                if tb:
+                    assert res["ops"][k] == r["ops"], (mode, l1, k)
 
 
 def test_short_read_against_long_target_falls_back_to_int32(al):

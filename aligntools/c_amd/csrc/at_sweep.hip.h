@@ -178,13 +178,16 @@ struct Slot {
 
 /* The pointer matrix: LDS, or a per-wave global slot (stores are fire-and-forget coalesced rows;
  * the traceback reads them back L2-served after the wave's stores have been acknowledged). */
+#ifndef AT_DIAG_NO_STORE
+#define AT_DIAG_NO_STORE 0   /* 1: throw-away build that drops the pointer stores to HBM (what do they cost?); results are no alignments */
+#endif
 template <bool LDS>
 struct PtrStore {
 	uint32_t *g;
 	AT_DEV void st(int i, uint32_t v) const
 	{
 		if constexpr (LDS) at_lds[i] = v;
-		else g[i] = v;
+		else if (!AT_DIAG_NO_STORE) g[i] = v;
 	}
 	AT_DEV uint32_t ld(int i) const
 	{
@@ -192,8 +195,8 @@ struct PtrStore {
 		else return __hip_atomic_load(g + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   /* sc1: bypasses this CU's L1 */
 	}
 	/* 16 / 8 bytes of one lane at once (global slot only; i is a multiple of 4 / 2 words) */
-	AT_DEV void st4(int i, uint32_t v0, uint32_t v1, uint32_t v2, uint32_t v3) const { *(uint4 *)(g + i) = make_uint4(v0, v1, v2, v3); }
-	AT_DEV void st2(int i, uint32_t v0, uint32_t v1) const { *(uint2 *)(g + i) = make_uint2(v0, v1); }
+	AT_DEV void st4(int i, uint32_t v0, uint32_t v1, uint32_t v2, uint32_t v3) const { if (!AT_DIAG_NO_STORE) *(uint4 *)(g + i) = make_uint4(v0, v1, v2, v3); }
+	AT_DEV void st2(int i, uint32_t v0, uint32_t v1) const { if (!AT_DIAG_NO_STORE) *(uint2 *)(g + i) = make_uint2(v0, v1); }
 	AT_DEV void ready() const   /* before the first ld of a pair */
 	{
 		if constexpr (LDS) __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");

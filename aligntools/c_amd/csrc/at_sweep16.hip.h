@@ -39,6 +39,15 @@
 #define AT_WALK_AHEAD 4   /* fit walks: pointer words loaded ahead along the current run (C4: 2 -> 1.96, 4 -> 2.07, 8 -> 2.01 TCUPS) */
 #endif
 #ifndef AT_WALK_PRIO
+#ifndef AT_DIAG_NO_WALK
+#define AT_DIAG_NO_WALK 0   /* 1: throw-away build without the traceback walks (what do they cost?); every pair reports 0 ops */
+#endif
+#ifndef AT_GLOBAL_WALK_AHEAD
+#define AT_GLOBAL_WALK_AHEAD 1   /* global walks cross the whole matrix like fit ones: the same look-ahead along the current run, where 4 .. 16
+                                  * walks share a wavefront (150 x 150: 2 448 -> 2 778 GCUPS, 250 x 250: 2 065 -> 2 344).  Not on the 64-lane
+                                  * groups, whose two walks per wavefront gain nothing (C3 with launches in flight 2 977 -> 2 997) and lose
+                                  * alone on the chip (2 138 -> 1 915) */
+#endif
 #define AT_WALK_PRIO 2    /* s_setprio of a wave while it walks: the walk is a chain of dependent loads with a few instructions in
                           * between, which should not queue behind the other waves' sweeps (C3 +2.5 %, C4 +1 %; 0 = off) */
 #endif
@@ -719,7 +728,8 @@ __global__ __launch_bounds__(64, AT_WAVES16(G, K)) void at_sweep16(const Sweep16
 					const int glane = g * G;
 					int guard = l1 + l2 + 2;
 					if (AT_WALK_PRIO) __builtin_amdgcn_s_setprio(AT_WALK_PRIO);
-					if (ok && OVL) {
+					if (AT_DIAG_NO_WALK) {
+					} else if (ok && OVL) {
 						/* overlap (trace_back_overlap :896-922): the cell's pointer is the move -- LEFT 3: ('-', s2[--j]),
 						 * DIAGONAL 2: both, RIGHT 1: (s1[--i], '-') -- until column 0 */
 						while (cj > 0 && --guard >= 0) {
@@ -734,14 +744,14 @@ __global__ __launch_bounds__(64, AT_WAVES16(G, K)) void at_sweep16(const Sweep16
 							ci -= nb != 3; cj -= nb != 1;
 						}
 						if (guard < 0) ok = false;
-					} else if (ok && ISFIT) {
+					} else if (ok && (ISFIT || (AT_GLOBAL_WALK_AHEAD && MODE == K_GLOBAL && G < 64))) {
 						/* fit: the walk crosses the whole read, and with the jump state a run of JUMP ops crosses hundreds of
 						 * columns (C4: 380 ops per pair on average), every op a dependent load from HBM.  Runs are predictable:
 						 * while the state does not change the walk keeps its direction (LOW up, MID diagonal, UPP / JUMP left).
 						 * So the pointer words of the next four cells along the current direction are loaded together and
 						 * consumed while the state stays what it was: one round trip to HBM per run of four instead of one per op. */
 						constexpr int AHEAD = AT_WALK_AHEAD;
-						while (ci > 0) {
+						while (ci > 0 && (ISFIT || cj > 0)) {     /* (global, trace_back_gla :384-397: until either index is 0, then the padding loops) */
 							if (cj <= 0 || cnt >= l1 + l2) { ok = false; break; }   /* (a walk never has more ops than its slot holds) */
 							const int di = st >= 2 ? 1 : 0, dj = st == 3 ? 0 : 1;
 							uint32_t w[AHEAD];
@@ -774,6 +784,12 @@ __global__ __launch_bounds__(64, AT_WAVES16(G, K)) void at_sweep16(const Sweep16
 								}
 							}
 							if (!ok) break;
+						}
+						if constexpr (MODE == K_GLOBAL) {                     /* padding loops :398-407 */
+							if (ok) {
+								while (cj > 0) { ops[cnt++] = 2; --cj; }
+								while (ci > 0) { ops[cnt++] = 1; --ci; }
+							}
 						}
 					} else if (ok) {
 						/* local / global: one pointer cell per op.  The state machine is written with selects, not branches: the

@@ -48,6 +48,10 @@
                                   * groups, whose two walks per wavefront gain nothing (C3 with launches in flight 2 977 -> 2 997) and lose
                                   * alone on the chip (2 138 -> 1 915) */
 #endif
+#ifndef AT_LOCAL_WALK_AHEAD
+#define AT_LOCAL_WALK_AHEAD 1    /* and local ones, although those of unrelated reads are a dozen ops long (C2 on the 8-lane groups: 2 966 ->
+                                  * 3 042 GCUPS with launches in flight, 2 266 -> 2 447 alone; on 16-lane groups round 1 had measured -4 %) */
+#endif
 #define AT_WALK_PRIO 2    /* s_setprio of a wave while it walks: the walk is a chain of dependent loads with a few instructions in
                           * between, which should not queue behind the other waves' sweeps (C3 +2.5 %, C4 +1 %; 0 = off) */
 #endif
@@ -744,7 +748,7 @@ __global__ __launch_bounds__(64, AT_WAVES16(G, K)) void at_sweep16(const Sweep16
 							ci -= nb != 3; cj -= nb != 1;
 						}
 						if (guard < 0) ok = false;
-					} else if (ok && (ISFIT || (AT_GLOBAL_WALK_AHEAD && MODE == K_GLOBAL && G < 64))) {
+					} else if (ok && (ISFIT || (AT_GLOBAL_WALK_AHEAD && MODE == K_GLOBAL && G < 64) || (AT_LOCAL_WALK_AHEAD && MODE == K_LOCAL && G < 64))) {
 						/* fit: the walk crosses the whole read, and with the jump state a run of JUMP ops crosses hundreds of
 						 * columns (C4: 380 ops per pair on average), every op a dependent load from HBM.  Runs are predictable:
 						 * while the state does not change the walk keeps its direction (LOW up, MID diagonal, UPP / JUMP left).
@@ -752,6 +756,7 @@ __global__ __launch_bounds__(64, AT_WAVES16(G, K)) void at_sweep16(const Sweep16
 						 * consumed while the state stays what it was: one round trip to HBM per run of four instead of one per op. */
 						constexpr int AHEAD = AT_WALK_AHEAD;
 						while (ci > 0 && (ISFIT || cj > 0)) {     /* (global, trace_back_gla :384-397: until either index is 0, then the padding loops) */
+							if (MODE == K_LOCAL && st == 0) break;              /* HOME :788-791 (the cell that pointed home has been emitted) */
 							if (cj <= 0 || cnt >= l1 + l2) { ok = false; break; }   /* (a walk never has more ops than its slot holds) */
 							const int di = st >= 2 ? 1 : 0, dj = st == 3 ? 0 : 1;
 							uint32_t w[AHEAD];

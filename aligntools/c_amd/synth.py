@@ -50,3 +50,47 @@ def mutate_pairs(blob, l1, l2, seed, sub=0.05):
     mask = rng.random((blob.shape[0], n)) < sub
     out[:, l1:l1 + n][mask] = _ACGT[rng.integers(0, 4, size=int(mask.sum()))]
     return out
+
+
+def _uniform01(seed, first_pair, npairs, ncols, stream):
+    """[npairs, ncols] floats in [0, 1), a function of (seed, stream, pair index, column) only -- any shard, any rank."""
+    with np.errstate(over="ignore"):
+        idx = np.arange(first_pair, first_pair + npairs, dtype=np.uint64)
+        base = _splitmix64(idx * np.uint64(0x100000001B3) + np.uint64(seed) + np.uint64(stream) * np.uint64(0xD1B54A32D192ED03))
+        cols = np.arange(ncols, dtype=np.uint64)
+        r = _splitmix64(base[:, None] + cols[None, :] * np.uint64(0x9E3779B97F4A7C15))
+    return (r >> np.uint64(11)).astype(np.float64) * (1.0 / (1 << 53))
+
+
+def read_windows(blob, l1, l2, seed, first_pair=0, sub=0.05, ins=0.02, dele=0.02):
+    """The C4 input of SURVEY.md 8(d): for every other pair (even pair index) the read (s1) is a mutated window of its contig
+    (s2) -- a window start uniform over the contig, then 5 % substitutions, 2 % inserted and 2 % deleted bases, l1 bases in
+    the end; the other pairs keep their unrelated uniform read.  Deterministic per pair index."""
+    n = blob.shape[0]
+    out = blob.copy()
+    if l2 <= l1 + 16:
+        return out
+    u = _uniform01(seed, first_pair, n, 1, 1)[:, 0]
+    start = (u * (l2 - l1 - 16)).astype(np.int64) + 4
+    is_del = _uniform01(seed, first_pair, n, l1, 2) < dele      # the contig base before this read base is skipped
+    is_ins = _uniform01(seed, first_pair, n, l1, 3) < ins       # this read base is new, the contig does not advance
+    src = start[:, None] + np.arange(l1)[None, :] + np.cumsum(is_del, axis=1) - np.cumsum(is_ins, axis=1)
+    src = np.clip(src, 0, l2 - 1)
+    contig = blob[:, l1:l1 + l2]
+    read = np.take_along_axis(contig, src, axis=1)
+    rnd = _uniform01(seed, first_pair, n, l1, 4)
+    newbase = _ACGT[(rnd * 4).astype(np.int64) & 3]
+    change = is_ins | (_uniform01(seed, first_pair, n, l1, 5) < sub)
+    read = np.where(change, newbase, read)
+    even = ((np.arange(first_pair, first_pair + n) & 1) == 0)
+    out[even, :l1] = read[even]
+    return out
+
+
+def workload_blob(mode, use_jump, seed, npairs, l1, l2, first_pair=0):
+    """The synthetic batch of one bench workload: uniform ACGT pairs; for fit with the jump state (C4) every other read is a
+    mutated window of its contig."""
+    blob = synth_pairs_blob(seed, npairs, l1, l2, first_pair)
+    if mode == "fit" and use_jump:
+        blob = read_windows(blob, l1, l2, seed, first_pair)
+    return blob

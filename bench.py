@@ -160,7 +160,7 @@ def main():
     import torch
     import torch.distributed as dist
     import aligntools.c_amd as A
-    from aligntools.c_amd.synth import synth_pairs_blob
+    from aligntools.c_amd.synth import synth_pairs_blob, workload_blob
 
     local_rank %= max(1, torch.cuda.device_count())   # (a rehearsal may put several ranks on one card)
     torch.cuda.set_device(local_rank)
@@ -212,7 +212,7 @@ def main():
         blob = synth_pairs_blob(seed, nreads // 2, l1, l2)           # 25k rows of two 1 kbp reads
         plist = [(row[k * l1:(k + 1) * l1].tobytes(), b"") for row in blob for k in range(2)]
     else:
-        blob = synth_pairs_blob(seed, pairs, l1, l2, first_pair=rank * pairs)
+        blob = workload_blob(mode, use_jump, seed, pairs, l1, l2, first_pair=rank * pairs)   # (C4: every other read is a mutated window of its contig)
         plist = [(row[:l1].tobytes(), row[l1:].tobytes()) for row in blob]
     words, woff1, woff2, len1, len2, bits = A.pack_pairs(plist, bits=args.bits)
     tb = (not args.no_traceback) and mode != "edit" and not allpairs

@@ -29,11 +29,11 @@ def main():
     ap.add_argument("--sites", default="")
     a = ap.parse_args()
     import oracle as O
-    from aligntools.c_amd.synth import synth_pairs_blob
+    from aligntools.c_amd.synth import workload_blob
     m, u, o, e, j = [int(x) for x in a.scoring.split(",")]
     sites = [int(x) for x in a.sites.split("|")] if a.sites else []
     T = a.threads or min(os.cpu_count() or 1, 16)
-    blob = synth_pairs_blob(a.seed, a.pairs, a.l1, a.l2).tobytes()
+    blob = workload_blob(a.mode, bool(a.use_jump), a.seed, a.pairs, a.l1, a.l2).tobytes()   # the same batch bench.py sweeps on the GPU
     mode = O.MODE_NAMES[a.mode]
     kind = "reference" if O.have_ref() else "port"
     per = a.l1 + a.l2

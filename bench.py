@@ -332,6 +332,7 @@ def main():
             r = step(k)
             evs[k][1].record()
             finish(k, r)
+    t_issued = time.perf_counter()   # (the host has queued every step; what remains is the GPU draining them)
     for w in fixed_work:
         if w is not None:
             w.wait()
@@ -421,6 +422,7 @@ def main():
                              traffic=traffic,
                              kernel=("at_sweep16" if "packed16" in al.last_config else "at_myers" if "myers" in al.last_config else "at_sweep") + "<%s>" % mode,
                              kernel_avg_ms=kern_avg_ms, kernel_min_ms=kern_ms[0], kernel_alone_ms=kern_iso_ms, launches_in_flight=S,
+                             host_issue_ms_per_step=(t_issued - t0) * 1e3 / max(1, args.steps),
                              gcups_one_launch_at_a_time=float(pairs) * l1 * l2 / (kern_iso_ms * 1e-3) / 1e9,
                              # the HBM view BASELINE.json asks for: ALGORITHMIC bytes of a launch over its HIP-event duration
                              hbm={"achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,

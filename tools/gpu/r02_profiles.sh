@@ -42,3 +42,7 @@ done
 timeout -k 10 300 python3 tools/ragged_rate.py > $O/ragged_rate.txt 2>&1 || true
 timeout -k 10 300 python3 tools/host_path_rate.py > $O/host_path_rate.txt 2>&1 || true
 echo "sweeps done"
+# N > 1 pipeline rehearsals on the one card: RCCL world of 1 under torch.distributed.run, gloo world of 2 sharing the GPU
+timeout -k 10 300 python3 -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29611 bench.py --gpus 1 --steps 20 --warmup 5 --no-cpu-baseline > $O/dist_nccl1.json 2> $O/dist_nccl1.err || true
+timeout -k 10 300 python3 -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29612 bench.py --gpus 2 --steps 10 --warmup 3 --no-cpu-baseline --backend gloo --workload C4 --pairs 20000 > $O/dist_gloo2_C4.json 2> $O/dist_gloo2_C4.err || true
+echo "rehearsals done"

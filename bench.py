@@ -13,12 +13,15 @@ over the whole batch with the packed inputs already resident in HBM.
 
 Multi-GPU: pairs are independent, so each rank aligns its own 100k-pair shard
 (weak scaling); rank 0 broadcasts the scoring block over RCCL before the timed
-region and every step's results are gathered to all ranks over RCCL: the
-fixed-size part (score, end cell, state, CIGAR length: 20 B/pair) with an
-asynchronous all_gather that overlaps the following steps' kernels, the CIGARs
-(ops strings) in two phases -- compacted on the GPU; sizes first (they are the
-gathered CIGAR lengths: every rank sums them per peer), then one padded payload
-that travels while the following steps compute.
+region and every step's results are gathered to all ranks over RCCL, the
+results of `--gather-every` (8) consecutive steps in one collective (fewer,
+larger collectives, all of them on a communication stream of their own behind
+events of the sweep streams): the fixed-size part (score, end cell, state,
+CIGAR length: 20 B/pair) with an asynchronous all_gather; the CIGARs (ops
+strings) in two phases -- compacted on the GPU step by step; sizes first (they
+are the gathered CIGAR lengths: every rank sums them per peer and step), then
+one payload per group, padded to the largest, that travels while the next
+group computes.
 
 Steps alternate over `--streams` HIP streams (default 3), each with its own
 handle (workspace, work queue) and output buffers, so up to three launches are
@@ -131,6 +134,8 @@ def main():
     ap.add_argument("--l2", type=int, default=0, help="override the workload's second length (diagnostic)")
     ap.add_argument("--no-uniform-promise", action="store_true",
                     help="call at_align_batch_device with uniform_shape = 0: the device checks the shapes itself (diagnostic)")
+    ap.add_argument("--gather-every", type=int, default=8,
+                    help="N > 1: steps whose results travel in one collective (fixed-size results and CIGAR payload each)")
     ap.add_argument("--no-cigar-gather", action="store_true", help="N > 1: gather only the fixed-size results (diagnostic)")
     ap.add_argument("--no-gather", action="store_true", help="N > 1: no per-step collective at all (diagnostic)")
     ap.add_argument("--no-render", action="store_true",
@@ -223,39 +228,52 @@ def main():
     d_len2 = torch.from_numpy(len2).to(dev)
     ops_off = np.arange(pairs, dtype=np.int64) * (l1 + l2)
     d_ops_off = torch.from_numpy(ops_off).to(dev)
-    # score, end_i, end_j, state -- two buffers: step k+1 must not overwrite what step k's all_gather still reads
-    # (row 4 = nops, the CIGAR lengths)
-    d_res2 = [torch.zeros((5, pairs), dtype=torch.int32, device=dev) for _ in range(NB)]
+    # score, end_i, end_j, state, nops (the CIGAR lengths) of a step: [5, pairs] int32.
+    # N = 1: NB buffer sets used in turn.  N > 1: the results of G consecutive steps form one group buffer [G, 5, pairs] that is
+    # gathered with ONE collective (fewer, larger collectives; the sweep streams carry no communication at all), NGB sets in turn.
+    G = max(1, args.gather_every) if use_dist else 1
+    NGB = 3
+    if use_dist:
+        grp_res = [torch.zeros((G, 5, pairs), dtype=torch.int32, device=dev) for _ in range(NGB)]
+        res_of = lambda k: grp_res[(k // G) % NGB][k % G]
+    else:
+        d_res2 = [torch.zeros((5, pairs), dtype=torch.int32, device=dev) for _ in range(NB)]
+        res_of = lambda k: d_res2[k % NB]
     d_opss = [torch.zeros(pairs * (l1 + l2) + 64, dtype=torch.uint8, device=dev) if tb else None for _ in range(S)]
     rend = tb and not args.no_render
     d_r1s = [torch.zeros(pairs * (l1 + l2) + 64, dtype=torch.uint8, device=dev) if rend else None for _ in range(S)]
     d_r2s = [torch.zeros(pairs * (l1 + l2) + 64, dtype=torch.uint8, device=dev) if rend else None for _ in range(S)]
-    gathered = [torch.empty((world * 5, pairs), dtype=torch.int32, device=dev) for _ in range(NB)] if use_dist else None
-    fixed_work = [None] * NB
-    if use_dist:   # set-up, not a step: the first collective of a shape builds RCCL's channels (~0.1 s)
-        dist.all_gather_into_tensor(gathered[0], d_res2[0])
+    gath = use_dist and not args.no_gather
+    # CIGAR gather: the ops slots of every step are compacted on the GPU into that step's row of the group's
+    # payload buffer; the per-rank, per-step totals come out of the fixed-size gather (sums of the gathered CIGAR lengths); then
+    # ONE payload per group, every row padded to the largest total.  The payload of group g travels while group g + 1 computes.
+    cig = gath and tb and not args.no_cigar_gather
+    if gath:
+        comm_stream = torch.cuda.Stream(device=dev)      # all communication is queued here, behind events of the sweep streams
+        gathered = [torch.empty((world, G, 5, pairs), dtype=torch.int32, device=dev) for _ in range(NGB)]
+        busy = [[] for _ in range(NGB)]                    # the collectives that still read or write each buffer set
+        grp_rows = [0] * NGB                               # steps in the group that last used the set (the last group may be short)
+        step_ev = [torch.cuda.Event() for _ in range(S)]   # "this stream has finished its latest step"
+        dist.all_gather_into_tensor(gathered[0].view(world * G, 5, pairs), grp_res[0])   # set-up, not a step: the first collective of a shape builds RCCL's channels (~0.1 s)
         torch.cuda.synchronize()
-    # CIGAR gather: the ops slots are compacted on the GPU; the per-rank totals come out of the fixed-size
-    # gather (sums of the peers' CIGAR lengths); then one payload padded to the largest total.  The payload of step k travels while later steps compute.
-    cig = use_dist and tb and not args.no_cigar_gather and not args.no_gather
     if cig:
         cap = pairs * (l1 + l2)
-        d_packed = [torch.zeros(cap + 4096, dtype=torch.uint8, device=dev) for _ in range(NB)]
-        d_poff = [torch.zeros(pairs + 1, dtype=torch.int64, device=dev) for _ in range(NB)]
-        alltot = [torch.zeros(world, dtype=torch.int64, device=dev) for _ in range(NB)]
-        h_tot = [torch.zeros(world, dtype=torch.int64).pin_memory() for _ in range(NB)]
-        tot_ev = [torch.cuda.Event() for _ in range(NB)]
-        allpay = [torch.empty(world * (cap + 4096), dtype=torch.uint8, device=dev) for _ in range(NB)]   # worst case, up front
-        pay_work = [None] * NB
-        pay_pad = [0] * NB
+        grp_packed = [torch.zeros((G, cap + 4096), dtype=torch.uint8, device=dev) for _ in range(NGB)]
+        d_poff = [torch.zeros(pairs + 1, dtype=torch.int64, device=dev) for _ in range(S)]
+        alltot = [torch.zeros((world, G), dtype=torch.int64, device=dev) for _ in range(NGB)]
+        h_tot = [torch.zeros((world, G), dtype=torch.int64).pin_memory() for _ in range(NGB)]
+        tot_ev = [torch.cuda.Event() for _ in range(NGB)]
+        pay_stage = [None] * NGB                           # [rows, pad] contiguous copy of the group's payload rows (sized on first use)
+        allpay = [None] * NGB
+        pay_pad = [0] * NGB
 
     def step(k):
-        d_res = d_res2[k % NB]
+        d_res = res_of(k)
         al, d_ops = als[k % S], d_opss[k % S]
         stream = torch.cuda.current_stream().cuda_stream
-        if fixed_work[k % NB] is not None:   # the gather of step k-NB still reads this buffer set
-            fixed_work[k % NB].wait()
-            fixed_work[k % NB] = None
+        if gath:   # the collectives of the group that last used this buffer set must be done before a step writes into it
+            for wk in busy[(k // G) % NGB]:
+                wk.wait()
         if allpairs:   # this rank's slice of the triangle, a different one every step
             first = ((k * world + rank) * pairs) % (nreads * (nreads - 1) // 2 - pairs)
             al.align_allpairs_device(A.MODES[mode], nreads, d_words.data_ptr(), bits, d_woff1.data_ptr(), d_len1.data_ptr(), l1,
@@ -275,37 +293,51 @@ def main():
             al.render_batch_device(pairs, d_words.data_ptr(), bits, d_woff1.data_ptr(), d_woff2.data_ptr(), d_res[1].data_ptr(),
                                    d_res[2].data_ptr(), d_ops.data_ptr(), d_ops_off.data_ptr(), d_res[4].data_ptr(),
                                    d_r1.data_ptr(), d_r2.data_ptr(), None, False, torch.cuda.current_stream().cuda_stream)
-        if not use_dist or args.no_gather:
-            return None
-        b = k % NB
-        if cig:
-            if pay_work[b] is not None:   # the payload gather of step k-2 read d_packed[b]
-                pay_work[b].wait()
-            al.compact_ops_device(pairs, d_ops.data_ptr(), d_ops_off.data_ptr(), d_res[4].data_ptr(), d_packed[b].data_ptr(),
-                                  cap, d_poff[b].data_ptr(), torch.cuda.current_stream().cuda_stream)
-        # gather the fixed-size results of this step (row 4, nops, are the CIGAR sizes: phase 1 of the CIGAR gather)
-        w = dist.all_gather_into_tensor(gathered[b], d_res, async_op=True)
-        if cig:   # every rank's payload size = the sum of its gathered nops, brought to the host behind this step's own work
-            w.wait()
-            torch.sum(gathered[b].view(world, 5, pairs)[:, 4, :].clamp(min=0), dim=1, dtype=torch.int64, out=alltot[b])
-            h_tot[b].copy_(alltot[b], non_blocking=True)
-            tot_ev[b].record()
-        fixed_work[b] = w
-        return w
+        if not gath:
+            return
+        if cig:        # this step's CIGARs, back to back, into its row of the group's payload buffer
+            al.compact_ops_device(pairs, d_ops.data_ptr(), d_ops_off.data_ptr(), d_res[4].data_ptr(),
+                                  grp_packed[(k // G) % NGB][k % G].data_ptr(), cap, d_poff[k % S].data_ptr(),
+                                  torch.cuda.current_stream().cuda_stream)
+        step_ev[k % S].record()
 
-    def payload(k):
-        """Phase 2 of step k's CIGAR gather, issued LAG steps later: by then the sizes are on the host (the host
-        never waits for the newest launches, so several stay in flight), and the transfer overlaps the sweeps that
-        are already queued."""
-        b = k % NB
-        tot_ev[b].synchronize()
-        pad = (max(int(h_tot[b].max()), 1) + 4095) // 4096 * 4096
+    def gather_group(g, rows):
+        """Phase 1 for group g (`rows` steps): one all_gather of the fixed-size results (row 4 = nops: the CIGAR sizes), queued on the
+        communication stream behind the sweep streams' latest steps; then every rank's payload size per step = the sum of its
+        gathered nops, brought to the host."""
+        gb = g % NGB
+        grp_rows[gb] = rows
+        for ev in step_ev:
+            comm_stream.wait_event(ev)
+        with torch.cuda.stream(comm_stream):
+            w = dist.all_gather_into_tensor(gathered[gb].view(world * G, 5, pairs), grp_res[gb], async_op=True)
+            if cig:
+                w.wait()
+                torch.sum(gathered[gb][:, :, 4, :].clamp(min=0), dim=2, dtype=torch.int64, out=alltot[gb])
+                h_tot[gb].copy_(alltot[gb], non_blocking=True)
+                tot_ev[gb].record()
+        busy[gb] = [w]
+
+    def payload_group(g):
+        """Phase 2 for group g, issued one group later: by then its sizes are on the host (the host never waits for the newest
+        launches, so a whole group of them stays queued), and the transfer overlaps the sweeps of the group behind it."""
+        gb = g % NGB
+        rows = grp_rows[gb]
+        tot_ev[gb].synchronize()
+        pad = (max(int(h_tot[gb][:, :rows].max()), 1) + 4095) // 4096 * 4096
         assert pad <= cap + 4096
-        pay_pad[b] = pad
-        # issued behind step k's own stream just before that stream's next sweep (step k+S) is queued: the host waits
-        # for nothing that the stream would not have to wait for anyway, and the transfer runs beside the sweeps
-        with torch.cuda.stream(streams[k % S]):
-            pay_work[b] = dist.all_gather_into_tensor(allpay[b][:world * pad], d_packed[b][:pad], async_op=True)
+        pay_pad[gb] = pad
+        if pay_stage[gb] is None or pay_stage[gb].numel() < G * pad:   # (first use, or a group with longer CIGARs than any before)
+            torch.cuda.synchronize()                    # (happens in the warm-up: every set is sized at once)
+            room = min(cap + 4096, pad + pad // 4)
+            for x in range(NGB):
+                if pay_stage[x] is None or pay_stage[x].numel() < G * room:
+                    pay_stage[x] = torch.empty(G * room, dtype=torch.uint8, device=dev)
+                    allpay[x] = torch.empty(world * G * room, dtype=torch.uint8, device=dev)
+        with torch.cuda.stream(comm_stream):
+            stage = pay_stage[gb][:rows * pad].view(rows, pad)
+            stage.copy_(grp_packed[gb][:rows, :pad])
+            busy[gb].append(dist.all_gather_into_tensor(allpay[gb][:world * rows * pad], stage.view(-1), async_op=True))
 
     def sync_all():
         torch.cuda.synchronize()
@@ -313,35 +345,39 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    for k in range(args.warmup):
-        with torch.cuda.stream(streams[k % S]):
-            w = finish(k, step(k))
-            if w is not None:
-                w.wait()
+    def run(nsteps, timed_events=None):
+        """Queue nsteps steps over the S streams; N > 1: gather every group of G steps (the last one may be short) and wait for
+        every collective before returning."""
+        for k in range(nsteps):
+            with torch.cuda.stream(streams[k % S]):
+                if timed_events is not None:
+                    timed_events[k][0].record()
+                r = step(k)
+                if timed_events is not None:
+                    timed_events[k][1].record()
+                finish(k, r)
+            if gath and (k % G == G - 1 or k == nsteps - 1):
+                g = k // G
+                gather_group(g, k % G + 1)
+                if cig and g >= 1:
+                    payload_group(g - 1)
+        t_issued = time.perf_counter()   # (the host has queued every step; what remains is the GPU draining them)
+        if gath and nsteps > 0:
             if cig:
-                payload(k)
-                pay_work[k % NB].wait()
+                payload_group((nsteps - 1) // G)
+            for works in busy:
+                for wk in works:
+                    wk.wait()
+        return t_issued
+
+    run(args.warmup)
     sync_all()
+    if gath:   # (the timed run starts with every buffer set free)
+        for works in busy:
+            del works[:]
     evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
     t0 = time.perf_counter()
-    for k in range(args.steps):
-        with torch.cuda.stream(streams[k % S]):
-            if cig and k >= LAG:
-                payload(k - LAG)
-            evs[k][0].record()
-            r = step(k)
-            evs[k][1].record()
-            finish(k, r)
-    t_issued = time.perf_counter()   # (the host has queued every step; what remains is the GPU draining them)
-    for w in fixed_work:
-        if w is not None:
-            w.wait()
-    if cig and args.steps > 0:
-        for k in range(max(0, args.steps - LAG), args.steps):
-            payload(k)
-        for w in pay_work:
-            if w is not None:
-                w.wait()
+    t_issued = run(args.steps, evs)
     sync_all()
     t1 = time.perf_counter()
     elapsed = torch.tensor([t1 - t0], dtype=torch.float64, device=dev)
@@ -362,35 +398,40 @@ def main():
         torch.cuda.synchronize()
         iso.append(ea.elapsed_time(eb))
     kern_iso_ms = min(iso)
-    # every buffer set holds the results of the same batch
-    if not allpairs:   # (all-vs-all sweeps a different slice of the triangle every step)
-        for b in range(1, min(NB, args.steps)):
-            assert torch.equal(d_res2[b], d_res2[0]), "buffer sets disagree"
-    d_ops = d_opss[(args.steps - 1) % S]
-    scores = d_res2[(args.steps - 1) % NB][0].cpu().numpy()
-    nops = d_res2[(args.steps - 1) % NB][4].cpu().numpy() if tb else np.zeros(pairs, dtype=np.int32)
+    # every step of the timed run holds the results of the same batch
+    last = args.steps - 1
+    if not allpairs and args.steps > 0:   # (all-vs-all sweeps a different slice of the triangle every step)
+        for k in range(max(0, last - (G * NGB if use_dist else NB) + 1), last):
+            assert torch.equal(res_of(k), res_of(last)), "buffer sets disagree"
+    d_ops = d_opss[last % S]
+    scores = res_of(last)[0].cpu().numpy()
+    nops = res_of(last)[4].cpu().numpy() if tb else np.zeros(pairs, dtype=np.int32)
     gather_info = None
-    if cig and args.steps > 0:
-        # what arrived: every rank's total is the sum of its gathered nops, and this rank's part of the payload is its
-        # own ops slots back to back
-        b = (args.steps - 1) % NB
-        g = gathered[b].cpu().numpy().reshape(world, 5, pairs)
-        tots = h_tot[b].numpy()
-        assert (g[:, 4, :].clip(min=0).sum(axis=1) == tots).all(), "CIGAR gather: sizes disagree with the gathered nops"
-        mine = allpay[b][rank * pay_pad[b]: rank * pay_pad[b] + int(tots[rank])].cpu().numpy()
-        slots = d_ops[:pairs * (l1 + l2)].cpu().numpy().reshape(pairs, l1 + l2)
-        assert (mine == slots[np.arange(l1 + l2)[None, :] < nops[:, None]]).all(), "CIGAR gather: payload differs from the ops slots"
-        gather_info = {"fixed_bytes_per_rank": 20 * pairs, "cigar_bytes_per_rank": int(tots[rank]),
-                       "cigar_payload_padded_to": int(pay_pad[b]), "phases": "sizes, then one padded payload; the payload of "
-                       "step k overlaps the sweeps of the steps queued behind it"}
+    if gath and args.steps > 0:
+        # what arrived: every rank's block of the last group, and in it this rank's own results
+        gb, row, rows = (last // G) % NGB, last % G, last % G + 1
+        gnp = gathered[gb].cpu().numpy()
+        assert (gnp[rank, :rows] == grp_res[gb][:rows].cpu().numpy()).all(), "fixed-size gather: own block differs"
+        gather_info = {"steps_per_collective": G, "fixed_bytes_per_rank_and_step": 20 * pairs}
+        if cig:
+            # every rank's total per step is the sum of its gathered nops, and this rank's part of the payload is its own ops
+            # slots back to back
+            tots = h_tot[gb].numpy()
+            assert (gnp[:, :rows, 4, :].clip(min=0).sum(axis=2) == tots[:, :rows]).all(), "CIGAR gather: sizes disagree with the gathered nops"
+            pad = pay_pad[gb]
+            mine = allpay[gb][:world * rows * pad].view(world, rows, pad)[rank, row, :int(tots[rank, row])].cpu().numpy()
+            slots = d_ops[:pairs * (l1 + l2)].cpu().numpy().reshape(pairs, l1 + l2)
+            assert (mine == slots[np.arange(l1 + l2)[None, :] < nops[:, None]]).all(), "CIGAR gather: payload differs from the ops slots"
+            gather_info.update({"cigar_bytes_per_rank_and_step": int(tots[rank, row]), "cigar_row_padded_to": int(pad),
+                                "phases": "per group of %d steps: one all_gather of the fixed-size results (sizes), then one padded "
+                                          "payload; both on a communication stream, the payload of group g beside the sweeps of group g + 1" % G})
     assert (scores > -(1 << 30)).all() and (nops >= 0).all(), "kernel reported a domain error"
     if rend and args.steps > 0:
         # the GPU-rendered strings of a sample equal what at_render (host, one pair) makes of the same ops
-        last = (args.steps - 1)
         h_r1 = d_r1s[last % S].cpu().numpy().tobytes()
         h_r2 = d_r2s[last % S].cpu().numpy().tobytes()
         h_ops = d_ops.cpu().numpy()
-        h_res = d_res2[last % NB].cpu().numpy()
+        h_res = res_of(last).cpu().numpy()
         for k in range(0, pairs, max(1, pairs // 64)):
             oo, nk = int(ops_off[k]), int(nops[k])
             a, b = al.render(h_ops[oo:oo + nk].tobytes(), plist[k][0], int(h_res[1][k]), plist[k][1], int(h_res[2][k]))

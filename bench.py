@@ -233,21 +233,29 @@ def main():
     # gathered with ONE collective (fewer, larger collectives; the sweep streams carry no communication at all), NGB sets in turn.
     G = max(1, args.gather_every) if use_dist else 1
     NGB = 3
+    grp_of, row_of = [], []      # step -> its group and its row in the group's buffers (plan_groups, per run)
     if use_dist:
         grp_res = [torch.zeros((G, 5, pairs), dtype=torch.int32, device=dev) for _ in range(NGB)]
-        res_of = lambda k: grp_res[(k // G) % NGB][k % G]
+        res_of = lambda k: grp_res[grp_of[k] % NGB][row_of[k]]
     else:
         d_res2 = [torch.zeros((5, pairs), dtype=torch.int32, device=dev) for _ in range(NB)]
         res_of = lambda k: d_res2[k % NB]
-    d_opss = [torch.zeros(pairs * (l1 + l2) + 64, dtype=torch.uint8, device=dev) if tb else None for _ in range(S)]
+    slot_bytes = pairs * (l1 + l2)
+    cig = use_dist and tb and not args.no_gather and not args.no_cigar_gather
+    if cig:   # the ops slots of a whole group stay until the group's CIGARs have been compacted (one compaction per group)
+        grp_ops = [torch.zeros(G * slot_bytes + 64, dtype=torch.uint8, device=dev) for _ in range(NGB)]
+        ops_of = lambda k: grp_ops[grp_of[k] % NGB][row_of[k] * slot_bytes:]
+    else:
+        d_opss = [torch.zeros(slot_bytes + 64, dtype=torch.uint8, device=dev) if tb else None for _ in range(S)]
+        ops_of = lambda k: d_opss[k % S]
     rend = tb and not args.no_render
     d_r1s = [torch.zeros(pairs * (l1 + l2) + 64, dtype=torch.uint8, device=dev) if rend else None for _ in range(S)]
     d_r2s = [torch.zeros(pairs * (l1 + l2) + 64, dtype=torch.uint8, device=dev) if rend else None for _ in range(S)]
     gath = use_dist and not args.no_gather
-    # CIGAR gather: the ops slots of every step are compacted on the GPU into that step's row of the group's
-    # payload buffer; the per-rank, per-step totals come out of the fixed-size gather (sums of the gathered CIGAR lengths); then
-    # ONE payload per group, every row padded to the largest total.  The payload of group g travels while group g + 1 computes.
-    cig = gath and tb and not args.no_cigar_gather
+    # CIGAR gather: the ops slots of a whole group are compacted on the GPU by ONE compaction on the communication
+    # stream (the sweep streams carry sweeps and rendering only); the per-rank, per-step totals come out of the fixed-size gather
+    # (sums of the gathered CIGAR lengths); then ONE payload per group, padded to the largest group total.  The payload of group g
+    # travels while group g + 1 computes.
     if gath:
         comm_stream = torch.cuda.Stream(device=dev)      # all communication is queued here, behind events of the sweep streams
         gathered = [torch.empty((world, G, 5, pairs), dtype=torch.int32, device=dev) for _ in range(NGB)]
@@ -257,22 +265,24 @@ def main():
         dist.all_gather_into_tensor(gathered[0].view(world * G, 5, pairs), grp_res[0])   # set-up, not a step: the first collective of a shape builds RCCL's channels (~0.1 s)
         torch.cuda.synchronize()
     if cig:
-        cap = pairs * (l1 + l2)
-        grp_packed = [torch.zeros((G, cap + 4096), dtype=torch.uint8, device=dev) for _ in range(NGB)]
-        d_poff = [torch.zeros(pairs + 1, dtype=torch.int64, device=dev) for _ in range(S)]
+        cap = G * slot_bytes
+        al_comm = A.Aligner(local_rank)                    # its workspace holds the compaction's scan
+        grp_packed = [torch.zeros(cap + 4096, dtype=torch.uint8, device=dev) for _ in range(NGB)]
+        grp_nops = [torch.zeros((G, pairs), dtype=torch.int32, device=dev) for _ in range(NGB)]   # the group's nops rows, contiguous
+        grp_ops_off = torch.arange(G * pairs, dtype=torch.int64, device=dev) * (l1 + l2)
+        d_poff = [torch.zeros(G * pairs + 1, dtype=torch.int64, device=dev) for _ in range(NGB)]
         alltot = [torch.zeros((world, G), dtype=torch.int64, device=dev) for _ in range(NGB)]
         h_tot = [torch.zeros((world, G), dtype=torch.int64).pin_memory() for _ in range(NGB)]
         tot_ev = [torch.cuda.Event() for _ in range(NGB)]
-        pay_stage = [None] * NGB                           # [rows, pad] contiguous copy of the group's payload rows (sized on first use)
-        allpay = [None] * NGB
+        allpay = [None] * NGB                              # (sized on first use)
         pay_pad = [0] * NGB
 
     def step(k):
         d_res = res_of(k)
-        al, d_ops = als[k % S], d_opss[k % S]
+        al, d_ops = als[k % S], ops_of(k)
         stream = torch.cuda.current_stream().cuda_stream
         if gath:   # the collectives of the group that last used this buffer set must be done before a step writes into it
-            for wk in busy[(k // G) % NGB]:
+            for wk in busy[grp_of[k] % NGB]:
                 wk.wait()
         if allpairs:   # this rank's slice of the triangle, a different one every step
             first = ((k * world + rank) * pairs) % (nreads * (nreads - 1) // 2 - pairs)
@@ -288,17 +298,13 @@ def main():
         return d_res
 
     def finish(k, d_res):
-        al, d_ops, d_r1, d_r2 = als[k % S], d_opss[k % S], d_r1s[k % S], d_r2s[k % S]
+        al, d_ops, d_r1, d_r2 = als[k % S], ops_of(k), d_r1s[k % S], d_r2s[k % S]
         if rend:       # ops (END -> START) -> the reference's two strings, in HBM
             al.render_batch_device(pairs, d_words.data_ptr(), bits, d_woff1.data_ptr(), d_woff2.data_ptr(), d_res[1].data_ptr(),
                                    d_res[2].data_ptr(), d_ops.data_ptr(), d_ops_off.data_ptr(), d_res[4].data_ptr(),
                                    d_r1.data_ptr(), d_r2.data_ptr(), None, False, torch.cuda.current_stream().cuda_stream)
         if not gath:
             return
-        if cig:        # this step's CIGARs, back to back, into its row of the group's payload buffer
-            al.compact_ops_device(pairs, d_ops.data_ptr(), d_ops_off.data_ptr(), d_res[4].data_ptr(),
-                                  grp_packed[(k // G) % NGB][k % G].data_ptr(), cap, d_poff[k % S].data_ptr(),
-                                  torch.cuda.current_stream().cuda_stream)
         step_ev[k % S].record()
 
     def gather_group(g, rows):
@@ -312,6 +318,10 @@ def main():
         with torch.cuda.stream(comm_stream):
             w = dist.all_gather_into_tensor(gathered[gb].view(world * G, 5, pairs), grp_res[gb], async_op=True)
             if cig:
+                # the group's CIGARs, back to back in (step, pair) order: one compaction over rows x pairs slots
+                grp_nops[gb].copy_(grp_res[gb][:, 4, :])
+                al_comm.compact_ops_device(rows * pairs, grp_ops[gb].data_ptr(), grp_ops_off.data_ptr(), grp_nops[gb].data_ptr(),
+                                           grp_packed[gb].data_ptr(), cap, d_poff[gb].data_ptr(), comm_stream.cuda_stream)
                 w.wait()
                 torch.sum(gathered[gb][:, :, 4, :].clamp(min=0), dim=2, dtype=torch.int64, out=alltot[gb])
                 h_tot[gb].copy_(alltot[gb], non_blocking=True)
@@ -324,20 +334,17 @@ def main():
         gb = g % NGB
         rows = grp_rows[gb]
         tot_ev[gb].synchronize()
-        pad = (max(int(h_tot[gb][:, :rows].max()), 1) + 4095) // 4096 * 4096
+        pad = (max(int(h_tot[gb][:, :rows].sum(dim=1).max()), 1) + 4095) // 4096 * 4096   # the largest group total of any rank
         assert pad <= cap + 4096
         pay_pad[gb] = pad
-        if pay_stage[gb] is None or pay_stage[gb].numel() < G * pad:   # (first use, or a group with longer CIGARs than any before)
+        if allpay[gb] is None or allpay[gb].numel() < world * pad:   # (first use, or a group with longer CIGARs than any before)
             torch.cuda.synchronize()                    # (happens in the warm-up: every set is sized at once)
-            room = min(cap + 4096, pad + pad // 4)
+            room = min(cap + 4096, (pad + pad // 4) // rows * G)
             for x in range(NGB):
-                if pay_stage[x] is None or pay_stage[x].numel() < G * room:
-                    pay_stage[x] = torch.empty(G * room, dtype=torch.uint8, device=dev)
-                    allpay[x] = torch.empty(world * G * room, dtype=torch.uint8, device=dev)
+                if allpay[x] is None or allpay[x].numel() < world * room:
+                    allpay[x] = torch.empty(world * room, dtype=torch.uint8, device=dev)
         with torch.cuda.stream(comm_stream):
-            stage = pay_stage[gb][:rows * pad].view(rows, pad)
-            stage.copy_(grp_packed[gb][:rows, :pad])
-            busy[gb].append(dist.all_gather_into_tensor(allpay[gb][:world * rows * pad], stage.view(-1), async_op=True))
+            busy[gb].append(dist.all_gather_into_tensor(allpay[gb][:world * pad], grp_packed[gb][:pad], async_op=True))
 
     def sync_all():
         torch.cuda.synchronize()
@@ -345,9 +352,22 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    def plan_groups(nsteps):
+        """Groups of G consecutive steps; the last step is a group of its own, so that what remains to be done once the last sweep
+        has finished (fixed-size gather, compaction, sizes to the host, payload) handles one step's results, not G."""
+        del grp_of[:], row_of[:]
+        k = 0
+        while k < nsteps:
+            n = min(G, nsteps - k)
+            if k + n == nsteps and n > 1:
+                n -= 1
+            grp_of.extend([len(set(grp_of))] * n)
+            row_of.extend(range(n))
+            k += n
+
     def run(nsteps, timed_events=None):
-        """Queue nsteps steps over the S streams; N > 1: gather every group of G steps (the last one may be short) and wait for
-        every collective before returning."""
+        """Queue nsteps steps over the S streams; N > 1: gather every group of steps and wait for every collective before returning."""
+        plan_groups(nsteps)
         for k in range(nsteps):
             with torch.cuda.stream(streams[k % S]):
                 if timed_events is not None:
@@ -356,15 +376,15 @@ def main():
                 if timed_events is not None:
                     timed_events[k][1].record()
                 finish(k, r)
-            if gath and (k % G == G - 1 or k == nsteps - 1):
-                g = k // G
-                gather_group(g, k % G + 1)
+            if gath and (k == nsteps - 1 or grp_of[k + 1] != grp_of[k]):
+                g = grp_of[k]
+                gather_group(g, row_of[k] + 1)
                 if cig and g >= 1:
                     payload_group(g - 1)
         t_issued = time.perf_counter()   # (the host has queued every step; what remains is the GPU draining them)
         if gath and nsteps > 0:
             if cig:
-                payload_group((nsteps - 1) // G)
+                payload_group(grp_of[nsteps - 1])
             for works in busy:
                 for wk in works:
                     wk.wait()
@@ -401,15 +421,15 @@ def main():
     # every step of the timed run holds the results of the same batch
     last = args.steps - 1
     if not allpairs and args.steps > 0:   # (all-vs-all sweeps a different slice of the triangle every step)
-        for k in range(max(0, last - (G * NGB if use_dist else NB) + 1), last):
+        for k in range(max(0, last - (G if use_dist else NB) + 1), last):
             assert torch.equal(res_of(k), res_of(last)), "buffer sets disagree"
-    d_ops = d_opss[last % S]
+    d_ops = ops_of(last)
     scores = res_of(last)[0].cpu().numpy()
     nops = res_of(last)[4].cpu().numpy() if tb else np.zeros(pairs, dtype=np.int32)
     gather_info = None
     if gath and args.steps > 0:
         # what arrived: every rank's block of the last group, and in it this rank's own results
-        gb, row, rows = (last // G) % NGB, last % G, last % G + 1
+        gb, row, rows = grp_of[last] % NGB, row_of[last], row_of[last] + 1
         gnp = gathered[gb].cpu().numpy()
         assert (gnp[rank, :rows] == grp_res[gb][:rows].cpu().numpy()).all(), "fixed-size gather: own block differs"
         gather_info = {"steps_per_collective": G, "fixed_bytes_per_rank_and_step": 20 * pairs}
@@ -419,10 +439,11 @@ def main():
             tots = h_tot[gb].numpy()
             assert (gnp[:, :rows, 4, :].clip(min=0).sum(axis=2) == tots[:, :rows]).all(), "CIGAR gather: sizes disagree with the gathered nops"
             pad = pay_pad[gb]
-            mine = allpay[gb][:world * rows * pad].view(world, rows, pad)[rank, row, :int(tots[rank, row])].cpu().numpy()
+            at = int(tots[rank, :row].sum())       # the group's payload is in (step, pair) order: the last step's CIGARs start here
+            mine = allpay[gb][:world * pad].view(world, pad)[rank, at:at + int(tots[rank, row])].cpu().numpy()
             slots = d_ops[:pairs * (l1 + l2)].cpu().numpy().reshape(pairs, l1 + l2)
             assert (mine == slots[np.arange(l1 + l2)[None, :] < nops[:, None]]).all(), "CIGAR gather: payload differs from the ops slots"
-            gather_info.update({"cigar_bytes_per_rank_and_step": int(tots[rank, row]), "cigar_row_padded_to": int(pad),
+            gather_info.update({"cigar_bytes_per_rank_and_step": int(tots[rank, row]), "cigar_group_payload_padded_to": int(pad),
                                 "phases": "per group of %d steps: one all_gather of the fixed-size results (sizes), then one padded "
                                           "payload; both on a communication stream, the payload of group g beside the sweeps of group g + 1" % G})
     assert (scores > -(1 << 30)).all() and (nops >= 0).all(), "kernel reported a domain error"
@@ -430,7 +451,7 @@ def main():
         # the GPU-rendered strings of a sample equal what at_render (host, one pair) makes of the same ops
         h_r1 = d_r1s[last % S].cpu().numpy().tobytes()
         h_r2 = d_r2s[last % S].cpu().numpy().tobytes()
-        h_ops = d_ops.cpu().numpy()
+        h_ops = d_ops[:slot_bytes].cpu().numpy()
         h_res = res_of(last).cpu().numpy()
         for k in range(0, pairs, max(1, pairs // 64)):
             oo, nk = int(ops_off[k]), int(nops[k])

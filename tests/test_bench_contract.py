@@ -43,3 +43,26 @@ def test_bench_refuses_gpus_without_launcher():
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
     p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2"], capture_output=True, text=True, timeout=120, env=env)
     assert p.returncode != 0 and "torch.distributed.run" in p.stderr and p.stdout.strip() == ""
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("world,backend,extra", [(1, "nccl", ["--steps", "11", "--warmup", "3", "--gather-every", "4"]),
+                                                 (2, "gloo", ["--steps", "7", "--warmup", "2", "--gather-every", "3", "--workload", "C4"])])
+def test_bench_under_the_launcher_gathers_groups_of_steps(world, backend, extra):
+    """The way the driver starts N > 1: `python -m torch.distributed.run … bench.py --gpus N`.  RCCL with a world of one (RCCL
+    refuses two ranks on one device) and gloo with two ranks sharing the test box's card run the whole pipeline -- scoring
+    broadcast, grouped fixed-size gathers, one CIGAR compaction and one padded payload per group, a last group of one step --
+    and bench.py's own checks (own block arrived, sizes = gathered nops, payload = ops slots) must hold on every rank."""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env["HSA_ENABLE_IPC_MODE_LEGACY"] = "0"
+    port = 29810 + world
+    p = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world), "--master-addr", "127.0.0.1",
+                        "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", str(world), "--pairs", "20000", "--no-cpu-baseline",
+                        "--backend", backend] + extra, capture_output=True, text=True, timeout=900, env=env, cwd=ROOT)
+    assert p.returncode == 0, p.stderr[-3000:]
+    lines = [x for x in p.stdout.splitlines() if x.strip().startswith("{")]
+    assert len(lines) == 1, p.stdout
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == world and d["scaling"] == "weak" and d["value"] > 0
+    g = d["config"]["gather"]
+    assert g["steps_per_collective"] == int(extra[extra.index("--gather-every") + 1]) and g["cigar_bytes_per_rank_and_step"] > 0

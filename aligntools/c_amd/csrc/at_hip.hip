@@ -310,8 +310,9 @@ struct Layout16 {
 
 /* Group width: reads of up to 152 bases run as 8 groups of 8 lanes x K rows (16 alignments per wave: 94 % of the
  * lane-steps inside a 150 x 150 matrix, the per-step overhead spread over 19 rows), up to 208 bases as 4 groups of 16
- * lanes (8 alignments per wave, 85 %; one group of 64 lanes: 59 %), 209..416 bases as 2 groups of 32 lanes, everything
- * else as one group of 64 lanes.  AT_GROUP = 16 / 64 caps the choice (A/B runs); ragged frames name their group width themselves. */
+ * lanes (8 alignments per wave, 85 %; one group of 64 lanes: 59 %) and so do 209..304 bases with 16 / 19 rows per lane,
+ * 305..416 bases as 2 groups of 32 lanes, everything
+ * else as one group of 64 lanes.  AT_GROUP = 16 / 32 / 64 caps the choice (A/B runs); ragged frames name their group width themselves. */
 static Layout16 layout16_for(bool tb, bool hasj, int l1, int l2, int ts, int force_g = 0, bool overlap = false)   /* force_g: 8 / 16 = ragged frames on that group width; 64 = tail */
 {
 	Layout16 L;
@@ -331,6 +332,11 @@ static Layout16 layout16_for(bool tb, bool hasj, int l1, int l2, int ts, int for
 	} else if ((force_g == 16 || g_forced != 64) && ts == 4 && l1 <= 208) {
 		L.g = 16;
 		L.k = l1 <= 64 ? 4 : l1 <= 80 ? 5 : l1 <= 96 ? 6 : l1 <= 112 ? 7 : (l1 <= 160 ? 10 : 13);
+	} else if (g_forced != 64 && g_forced != 32 && !force_g && ts == 4 && l1 > 208 && l1 <= 304) {
+		/* 250- and 300-base reads: still four groups of 16 lanes, 16 or 19 rows per lane (8 alignments per wave; AT_GROUP=32: the
+		 * two 32-lane groups below) */
+		L.g = 16;
+		L.k = l1 <= 256 ? 16 : 19;
 	} else if (g_forced != 64 && ts == 4 && l1 > 208 && l1 <= 416) {
 		/* 250- and 300-base reads: two groups of 32 lanes (4 alignments per wave); one group of 64 lanes would carry 2 and
 		 * cut 300 rows into a strip of 256 and one of 44 */

@@ -1052,13 +1052,16 @@ def test_packed_range_check_harsh_mismatch(al, mode):
 
 @pytest.mark.parametrize("mode", ["local", "global", "fit", "fitj"])
 def test_packed_32_lane_groups(al, mode):
-    """Reads of 209..416 bases (250- and 300-base reads) run as two groups of 32 lanes, 7 / 8 / 10 / 13 rows per lane: every
-    class edge, both alphabets, related and unrelated pairs, against the oracle."""
+    """Reads of 209..304 bases (250- and 300-base reads) run as four groups of 16 lanes with 16 / 19 rows per lane, 305..416 as two
+    groups of 32 lanes with 10 / 13 rows per lane, and with AT_GROUP=32 all of 209..416 on the 32-lane groups (7 / 8 / 10 / 13 rows):
+    every class edge, both alphabets, related and unrelated pairs, with and without tracebacks, against the oracle."""
     rng = random.Random(3232)
     uj = mode == "fitj"
     m = "fit" if uj else mode
-    for l1, l2, alpha in ((209, 209, "ACGT"), (224, 260, "ACGT"), (225, 225, "ACGTN"), (250, 250, "ACGT"), (256, 300, "ACGT"), (257, 257, "ACGT"),
-                          (300, 300, "ACGT"), (320, 400, "ACGTN"), (321, 321, "ACGT"), (416, 416, "ACGT")):
+    import os
+    for l1, l2, alpha, force32 in ((209, 209, "ACGT", 0), (224, 260, "ACGT", 1), (225, 225, "ACGTN", 1), (250, 250, "ACGT", 0), (250, 250, "ACGT", 1),
+                                   (256, 300, "ACGT", 0), (257, 257, "ACGT", 0), (257, 257, "ACGT", 1), (300, 300, "ACGT", 0), (300, 300, "ACGTN", 1),
+                                   (304, 2000, "ACGT", 0), (305, 305, "ACGT", 0), (320, 400, "ACGTN", 0), (321, 321, "ACGT", 0), (416, 416, "ACGT", 0)):
         pairs = []
         for k in range(24):
             a = "".join(rng.choice(alpha) for _ in range(l1))
@@ -1079,14 +1082,23 @@ def test_packed_32_lane_groups(al, mode):
             pairs.append((a, b))
         sc = (2, -2, -5, -2, -9) if mode != "global" else (1, -2, -4, -1, -9)
         al.set_scoring(*sc, uj, [50, 150, 250])
-        res = al.align_batch(m, pairs, render=False)
-        assert "packed16" in al.last_config, (l1, l2, al.last_config)
-        if "packed16 x16" in al.last_config:      # (scores x4 when x16 would leave 16 bits: one 64-lane group)
-            assert "2x32-lane groups" in al.last_config, (l1, l2, al.last_config)
+        if force32:
+            os.environ["AT_GROUP"] = "32"
+        try:
+            res = al.align_batch(m, pairs, render=False)
+            cfg = al.last_config
+            res0 = al.align_batch(m, pairs, traceback=False, render=False)
+        finally:
+            os.environ.pop("AT_GROUP", None)
+        assert "packed16" in cfg, (l1, l2, cfg)
+        if "packed16 x16" in cfg:      # (scores x4 when x16 would leave 16 bits: one 64-lane group)
+            assert ("2x32-lane groups" if force32 or l1 > 304 else "4x16-lane groups") in cfg, (l1, l2, cfg)
         for k, (x, y) in enumerate(pairs):
             r = O.align(O.MODE_NAMES[m], x, y, *sc, uj, [50, 150, 250])
             assert (int(res["score"][k]), int(res["end_i"][k]), int(res["end_j"][k]), int(res["state"][k]), res["ops"][k]) == \
                    (r["score"], r["end_i"], r["end_j"], r["state"], r["ops"]), (mode, l1, l2, k)
+            assert (int(res0["score"][k]), int(res0["end_i"][k]), int(res0["end_j"][k]), int(res0["state"][k])) == \
+                   (r["score"], r["end_i"], r["end_j"], r["state"]), (mode, l1, l2, k, "scores only")
 
 
 @pytest.mark.parametrize("mode", ["local", "global", "fit", "fitj"])

@@ -311,9 +311,9 @@ struct Layout16 {
 /* Group width: reads of up to 152 bases run as 8 groups of 8 lanes x K rows (16 alignments per wave: 94 % of the
  * lane-steps inside a 150 x 150 matrix, the per-step overhead spread over 19 rows), up to 208 bases as 4 groups of 16
  * lanes (8 alignments per wave, 85 %; one group of 64 lanes: 59 %) and so do 209..304 bases with 16 / 19 rows per lane,
- * 305..416 bases as 2 groups of 32 lanes, everything
+ * 305..608 bases as 2 groups of 32 lanes (10 .. 19 rows per lane), everything
  * else as one group of 64 lanes.  AT_GROUP = 16 / 32 / 64 caps the choice (A/B runs); ragged frames name their group width themselves. */
-static Layout16 layout16_for(bool tb, bool hasj, int l1, int l2, int ts, int force_g = 0, bool overlap = false)   /* force_g: 8 / 16 = ragged frames on that group width; 64 = tail */
+static Layout16 layout16_for(bool tb, bool hasj, int l1, int l2, int ts, int force_g = 0, bool overlap = false, int kmode = -1)   /* force_g: 8 / 16 = ragged frames on that group width; 64 = tail */
 {
 	Layout16 L;
 	const long long g_forced = env_ll("AT_GROUP", 0);
@@ -337,11 +337,15 @@ static Layout16 layout16_for(bool tb, bool hasj, int l1, int l2, int ts, int for
 		 * two 32-lane groups below) */
 		L.g = 16;
 		L.k = l1 <= 256 ? 16 : 19;
-	} else if (g_forced != 64 && ts == 4 && l1 > 208 && l1 <= 416) {
+	} else if (g_forced != 64 && ts == 4 && l1 > 208 &&
+	           l1 <= (force_g || g_forced == 32 ? 416 : kmode == at::K_LOCAL ? 608 : kmode == at::K_GLOBAL ? 512 : 416)) {
 		/* 250- and 300-base reads: two groups of 32 lanes (4 alignments per wave); one group of 64 lanes would carry 2 and
 		 * cut 300 rows into a strip of 256 and one of 44 */
 		L.g = 32;
-		L.k = l1 <= 224 ? 7 : l1 <= 256 ? 8 : l1 <= 320 ? 10 : 13;
+		/* 305 .. 608 bases: still one strip -- 10, 12, 13, 16 or 19 rows per lane (AT_GROUP=32: the round-1 classes only, 417+ on the
+		 * 64-lane groups).  16 rows only for local and global, 19 only for local: the others spill there (268 .. 612 bytes of
+		 * scratch per lane) and lose to the strips of the 64-lane group (global 560 / 608 bases: -4 %) */
+		L.k = l1 <= 224 ? 7 : l1 <= 256 ? 8 : l1 <= 320 ? 10 : l1 <= 384 && g_forced != 32 ? 12 : l1 <= 416 ? 13 : l1 <= 512 ? 16 : 19;
 	}
 	const int ng = 64 / L.g;
 	const int blk = L.g <= 16 ? 4 : 8;        /* BLK of at_sweep16 */
@@ -694,7 +698,7 @@ static int align_device(at_handle *h, int mode, int64_t npairs,
 		return fail(h, AT_ERR_ARG, "ragged packed launch outside its domain");   /* the host entry checks before it asks */
 	Layout16 P;
 	if (ts) {
-		P = layout16_for(tb, kmode == at::K_FITJ, max_len1, max_len2, ts, tail ? 64 : rag, kmode == at::K_OVERLAP);
+		P = layout16_for(tb, kmode == at::K_FITJ, max_len1, max_len2, ts, tail ? 64 : rag, kmode == at::K_OVERLAP, kmode);
 		/* A 64-lane packed wave carries 2 alignments where an int32 wave carries 1: fewer, longer work items.  A batch
 		 * that cannot give every resident wave one of them stays on the int32 kernel.  (10k x 1024^2 = 1.6 rounds: 1.96
 		 * packed vs 2.00 TCUPS int32 for a lone launch, 2.70 vs 2.13 with launches in flight; 61k pairs: 2.70 vs 2.19.) */

@@ -19,8 +19,10 @@ static at_sweep16_fn g2(int k, int store, bool tb)
 	default: return nullptr;
 	}
 }
+at_sweep16_fn AT_NAME(at_pick16_g32b)(int kmode, int k, int store, bool tb);
 at_sweep16_fn AT_NAME(at_pick16_g32)(int kmode, int k, int store, bool tb)
 {
+	if (k == 12 || k >= 16) return AT_NAME(at_pick16_g32b)(kmode, k, store, tb);
 	switch (kmode) {
 	case at::K_GLOBAL: return g2<at::K_GLOBAL>(k, store, tb);
 	case at::K_LOCAL: return g2<at::K_LOCAL>(k, store, tb);

@@ -154,7 +154,7 @@ AT_DEV int sat16(int v) { return v < -32768 ? -32768 : (v > 32767 ? 32767 : v); 
 
 /* second __launch_bounds__ argument = waves per SIMD the register allocator must leave room for */
 #ifndef AT_WAVES16
-#define AT_WAVES16(G, K) ((G) == 8 ? ((K) >= 16 ? 2 : (K) >= 10 ? 3 : 1) : (G) == 16 && (K) >= 16 ? 2 : ((G) == 16 || (G) == 32) && (K) >= 10 ? 3 : 1)
+#define AT_WAVES16(G, K) ((G) == 8 ? ((K) >= 16 ? 2 : (K) >= 10 ? 3 : 1) : ((G) == 16 && (K) >= 16) || ((G) == 32 && (K) >= 10) ? 2 : (G) == 16 && (K) >= 10 ? 3 : 1)
 #endif
 
 /* shift up by one lane inside a group of G lanes; lane 0 of each group keeps `old` */

@@ -132,6 +132,7 @@ def main():
                          "reads with N / protein)")
     ap.add_argument("--l1", type=int, default=0, help="override the workload's first length (diagnostic)")
     ap.add_argument("--l2", type=int, default=0, help="override the workload's second length (diagnostic)")
+    ap.add_argument("--no-jump", action="store_true", help="fit without the jump state (diagnostic: C4's shape on the plain fit kernels)")
     ap.add_argument("--no-uniform-promise", action="store_true",
                     help="call at_align_batch_device with uniform_shape = 0: the device checks the shapes itself (diagnostic)")
     ap.add_argument("--gather-every", type=int, default=8,
@@ -154,6 +155,8 @@ def main():
     mode, l1, l2, pairs, scoring, use_jump, sites, seed = WORKLOADS[args.workload]
     if args.pairs:
         pairs = args.pairs
+    if args.no_jump:
+        use_jump, sites = False, []
     l1, l2 = args.l1 or l1, args.l2 or l2
 
     # CPU baseline first (child process, before this process touches the GPU)

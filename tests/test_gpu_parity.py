@@ -1052,8 +1052,8 @@ def test_packed_range_check_harsh_mismatch(al, mode):
 
 @pytest.mark.parametrize("mode", ["local", "global", "fit", "fitj"])
 def test_packed_32_lane_groups(al, mode):
-    """Reads of 209..304 bases (250- and 300-base reads) run as four groups of 16 lanes with 16 / 19 rows per lane, 305..416 as two
-    groups of 32 lanes with 10 / 13 rows per lane, and with AT_GROUP=32 all of 209..416 on the 32-lane groups (7 / 8 / 10 / 13 rows):
+    """Reads of 209..304 bases (250- and 300-base reads) run as four groups of 16 lanes with 16 / 19 rows per lane, 305..608 as two
+    groups of 32 lanes with 10 / 12 / 13 / 16 / 19 rows per lane, and with AT_GROUP=32 all of 209..416 on the 32-lane groups (7 / 8 / 10 / 13 rows):
     every class edge, both alphabets, related and unrelated pairs, with and without tracebacks, against the oracle."""
     rng = random.Random(3232)
     uj = mode == "fitj"
@@ -1061,7 +1061,9 @@ def test_packed_32_lane_groups(al, mode):
     import os
     for l1, l2, alpha, force32 in ((209, 209, "ACGT", 0), (224, 260, "ACGT", 1), (225, 225, "ACGTN", 1), (250, 250, "ACGT", 0), (250, 250, "ACGT", 1),
                                    (256, 300, "ACGT", 0), (257, 257, "ACGT", 0), (257, 257, "ACGT", 1), (300, 300, "ACGT", 0), (300, 300, "ACGTN", 1),
-                                   (304, 2000, "ACGT", 0), (305, 305, "ACGT", 0), (320, 400, "ACGTN", 0), (321, 321, "ACGT", 0), (416, 416, "ACGT", 0)):
+                                   (304, 2000, "ACGT", 0), (305, 305, "ACGT", 0), (320, 400, "ACGTN", 0), (321, 321, "ACGT", 0), (321, 321, "ACGT", 1),
+                                   (384, 400, "ACGT", 0), (385, 385, "ACGTN", 0), (416, 416, "ACGT", 0), (417, 430, "ACGT", 0), (512, 512, "ACGT", 0),
+                                   (513, 520, "ACGT", 0), (608, 700, "ACGTN", 0), (609, 609, "ACGT", 0)):
         pairs = []
         for k in range(24):
             a = "".join(rng.choice(alpha) for _ in range(l1))
@@ -1092,7 +1094,9 @@ def test_packed_32_lane_groups(al, mode):
             os.environ.pop("AT_GROUP", None)
         assert "packed16" in cfg, (l1, l2, cfg)
         if "packed16 x16" in cfg:      # (scores x4 when x16 would leave 16 bits: one 64-lane group)
-            assert ("2x32-lane groups" if force32 or l1 > 304 else "4x16-lane groups") in cfg, (l1, l2, cfg)
+            hi32 = 416 if force32 else {"local": 608, "global": 512}.get(mode, 416)   # (16 rows per lane: local and global; 19: local)
+            want = "4x16-lane" if l1 <= 304 and not force32 else "2x32-lane" if l1 <= hi32 else "1x64-lane"
+            assert want + " groups" in cfg, (l1, l2, cfg)
         for k, (x, y) in enumerate(pairs):
             r = O.align(O.MODE_NAMES[m], x, y, *sc, uj, [50, 150, 250])
             assert (int(res["score"][k]), int(res["end_i"][k]), int(res["end_j"][k]), int(res["state"][k]), res["ops"][k]) == \

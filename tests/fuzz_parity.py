@@ -23,9 +23,11 @@ def draw_batch(rng):
     uj = mode == "fit" and rng.random() < 0.5
     n = rng.choice([1, 2, 3, 7, 16, 33, 64, 100])
     big = rng.random() < 0.06
-    hi = 1500 if big else rng.choice([8, 40, 70, 130, 200, 330])
+    hi = 1500 if big else rng.choice([8, 40, 70, 130, 200, 330, 650])   # (650: the 12- to 19-row classes of the 32-lane groups)
     if big:
         n = min(n, 7)
+    elif hi == 650:
+        n = min(n, 16)
     uniform = rng.random() < 0.5
     if uniform:
         l1 = rng.randint(1, hi)

@@ -332,7 +332,7 @@ static Layout16 layout16_for(bool tb, bool hasj, int l1, int l2, int ts, int for
 	} else if ((force_g == 16 || g_forced != 64) && ts == 4 && l1 <= 208) {
 		L.g = 16;
 		L.k = l1 <= 64 ? 4 : l1 <= 80 ? 5 : l1 <= 96 ? 6 : l1 <= 112 ? 7 : (l1 <= 160 ? 10 : 13);
-	} else if (g_forced != 64 && g_forced != 32 && !force_g && ts == 4 && l1 > 208 && l1 <= 304) {
+	} else if ((force_g == 16 || (!force_g && g_forced != 64 && g_forced != 32)) && ts == 4 && l1 > 208 && l1 <= 304) {
 		/* 250- and 300-base reads: still four groups of 16 lanes, 16 or 19 rows per lane (8 alignments per wave; AT_GROUP=32: the
 		 * two 32-lane groups below) */
 		L.g = 16;
@@ -694,7 +694,7 @@ static int align_device(at_handle *h, int mode, int64_t npairs,
 		/* overlap: the packed kernel exists with pointers only (scores alone: the int32 kernel's 3 instructions per cell win) */
 		if (kmode == at::K_OVERLAP && (!tb || getenv("AT_NO_PACKED_OVERLAP"))) ts = 0;
 	}
-	if (rag && (!ts || kmode > at::K_FITJ || max_len1 > (rag == 8 ? 152 : 208) || !d_order))
+	if (rag && (!ts || kmode > at::K_FITJ || max_len1 > (rag == 8 ? 152 : 304) || !d_order))
 		return fail(h, AT_ERR_ARG, "ragged packed launch outside its domain");   /* the host entry checks before it asks */
 	Layout16 P;
 	if (ts) {
@@ -979,14 +979,14 @@ static int align_host(at_handle *h, int mode, int64_t npairs, const uint8_t *seq
 	uint8_t *d_ops = (uint8_t *)(dout + 5 * b_len1);
 	int64_t *d_poff = (int64_t *)(dout + 5 * b_len1 + b_ops);   /* exclusive prefix sums of nops (tb only) */
 
-	/* ragged batch.  Affine alignments of reads (l1 <= 208, scores within 16 bits) go to the packed kernels in FRAMES
+	/* ragged batch.  Affine alignments of reads (l1 <= 304, scores within 16 bits) go to the packed kernels in FRAMES
 	 * (RAG kernels): a work item sweeps the extents its alignments need and every alignment keeps its own.
 	 *   local          pairs sorted by (rows-per-lane class of l1, l2), cut into buckets of similar l2, one launch per
 	 *                  bucket on the 16-lane groups; the alignments of an item may differ in l1 and l2
 	 *   global / fit   their end cells lie in row l1, so the alignments of an item share l1: pairs sorted by (l1, l2), every
 	 *                  run of equal l1 padded to whole work items by repeating its last pair (which is then computed twice,
 	 *                  same result to the same place), one launch per rows-per-lane class -- 8-lane groups up to 152 bases,
-	 *                  16-lane groups up to 208; an item sweeps the largest l2 among its own alignments
+	 *                  16-lane groups up to 304; an item sweeps the largest l2 among its own alignments
 	 * Everything else: the int32 kernel, pairs handed out largest first (the work queue is dynamic, so a big pair
 	 * picked up last would otherwise run alone at the end). */
 	int *d_order = nullptr;
@@ -999,7 +999,7 @@ static int align_host(at_handle *h, int mode, int64_t npairs, const uint8_t *seq
 		for (int64_t k = 0; k < npairs; ++k) { min1 = std::min(min1, len1[k]); min2 = std::min(min2, len2[k]); }
 		const bool affine = mode == AT_MODE_LOCAL || mode == AT_MODE_GLOBAL || mode == AT_MODE_FIT;
 		const int kmode_f = mode == AT_MODE_LOCAL ? at::K_LOCAL : mode == AT_MODE_GLOBAL ? at::K_GLOBAL : h->use_jump ? at::K_FITJ : at::K_FIT;
-		frames = affine && max1 <= 208 && min1 >= 1 && min2 >= 1 && npairs >= 64 && env_ll("AT_RAGGED_PACKED", 1) &&
+		frames = affine && max1 <= 304 && min1 >= 1 && min2 >= 1 && npairs >= 64 && env_ll("AT_RAGGED_PACKED", 1) &&
 		         packed_ok(h, mode, bits, max1, max2, 4, &th);
 		/* every frame is at most max1 x max2: if that one has no packed kernel (s2 too long for LDS), none is tried */
 		if (frames) {
@@ -1014,20 +1014,20 @@ static int align_host(at_handle *h, int mode, int64_t npairs, const uint8_t *seq
 		constexpr int gl = 16;
 		auto kclass = [](int l1) {
 			return gl == 8 ? (l1 <= 40 ? 5 : l1 <= 56 ? 7 : l1 <= 80 ? 10 : l1 <= 104 ? 13 : l1 <= 128 ? 16 : 19)
-			               : (l1 <= 64 ? 4 : l1 <= 80 ? 5 : l1 <= 96 ? 6 : l1 <= 112 ? 7 : l1 <= 160 ? 10 : 13);
+			               : (l1 <= 64 ? 4 : l1 <= 80 ? 5 : l1 <= 96 ? 6 : l1 <= 112 ? 7 : l1 <= 160 ? 10 : l1 <= 208 ? 13 : l1 <= 256 ? 16 : 19);
 		};
 		/* global / fit: (group width, rows per lane) of a read length */
 		auto gclass = [](int l1) { return l1 <= 152 ? 8 : 16; };
-		auto kclass2 = [](int l1) { return l1 <= 40 ? 5 : l1 <= 48 ? 6 : l1 <= 56 ? 7 : l1 <= 64 ? 8 : l1 <= 80 ? 10 : l1 <= 104 ? 13 : l1 <= 128 ? 16 : l1 <= 152 ? 19 : l1 <= 160 ? 10 : 13; };
+		auto kclass2 = [](int l1) { return l1 <= 40 ? 5 : l1 <= 48 ? 6 : l1 <= 56 ? 7 : l1 <= 64 ? 8 : l1 <= 80 ? 10 : l1 <= 104 ? 13 : l1 <= 128 ? 16 : l1 <= 152 ? 19 : l1 <= 160 ? 10 : l1 <= 208 ? 13 : l1 <= 256 ? 16 : 19; };
 		if (frames && mode == AT_MODE_LOCAL) {
-			/* (class descending, l2 descending, index ascending): a counting sort -- the key space is 6 x (max2 + 1) */
+			/* (class descending, l2 descending, index ascending): a counting sort -- the key space is 8 x (max2 + 1) */
 			auto kidx = [&](int l1) {   /* classes in descending order of rows per lane */
 				const int kc = kclass(l1);
 				return gl == 8 ? (kc == 19 ? 0 : kc == 16 ? 1 : kc == 13 ? 2 : kc == 10 ? 3 : kc == 7 ? 4 : 5)
-				               : (kc == 13 ? 0 : kc == 10 ? 1 : kc == 7 ? 2 : kc == 6 ? 3 : kc == 5 ? 4 : 5);
+				               : (kc == 19 ? 0 : kc == 16 ? 1 : kc == 13 ? 2 : kc == 10 ? 3 : kc == 7 ? 4 : kc == 6 ? 5 : kc == 5 ? 6 : 7);
 			};
 			const size_t span = (size_t)max2 + 1;
-			std::vector<int> start(6 * span + 1, 0);
+			std::vector<int> start(8 * span + 1, 0);
 			for (int64_t k = 0; k < npairs; ++k) ++start[(size_t)kidx(len1[k]) * span + (size_t)(max2 - len2[k]) + 1];
 			for (size_t q = 1; q < start.size(); ++q) start[q] += start[q - 1];
 			for (int64_t k = 0; k < npairs; ++k) order[(size_t)start[(size_t)kidx(len1[k]) * span + (size_t)(max2 - len2[k])]++] = (int)k;

@@ -586,16 +586,17 @@ def test_packed_kernels_on_byte_alphabets(al):
                        (r["score"], r["end_i"], r["end_j"], r["state"], r["ops"]), (alpha, mode, uj, k)
 
 
-@pytest.mark.parametrize("maxl", [208, 152])
+@pytest.mark.parametrize("maxl", [304, 208, 152])
 def test_ragged_local_batches_in_frames(al, maxl):
-    """Ragged local batches of reads (l1 <= 208) run on the packed kernel in frames: sorted into buckets of similar size,
+    """Ragged local batches of reads (l1 <= 304) run on the packed kernel in frames: sorted into buckets of similar size,
     every alignment keeping its own extents inside its bucket's frame.  All lengths from 1 up, unrelated and related
     pairs, score / end cell / ops against the oracle; a batch with one longer read falls back to the int32 kernel."""
     rng = random.Random(91)
     dna = lambda n: "".join(rng.choice("ACGT") for _ in range(n))
     pairs = []
     for k in range(3000):
-        l1 = rng.choice([1, 2, 15, 16, 17, 40, 41, 48, 49, 56, 57, 63, 64, 65, 80, 81, 96, 104, 105, 112, 113, 128, 129, 150, 152, 160, 161, 207, 208]) if k % 3 == 0 else rng.randint(1, 208)
+        l1 = rng.choice([1, 2, 15, 16, 17, 40, 41, 48, 49, 56, 57, 63, 64, 65, 80, 81, 96, 104, 105, 112, 113, 128, 129, 150, 152, 160, 161, 207, 208,
+                         209, 250, 256, 257, 300, 304]) if k % 3 == 0 else rng.randint(1, 304 if k % 2 else 208)
         l1 = min(l1, maxl)
         l2 = rng.randint(1, 260)
         a = dna(l1)
@@ -625,7 +626,7 @@ def test_ragged_local_batches_in_frames(al, maxl):
                 if tb:
                     assert res["ops"][k] == r["ops"], (sc, k)
     al.set_scoring(2, -2, -5, -2)
-    longer = pairs[:200] + [(dna(209), dna(100))]
+    longer = pairs[:200] + [(dna(305), dna(100))]
     res = al.align_batch("local", longer, render=False)
     assert "int32" in al.last_config
     r = O.align(O.LOCAL, longer[-1][0], longer[-1][1], 2, -2, -5, -2)
@@ -634,19 +635,20 @@ def test_ragged_local_batches_in_frames(al, maxl):
 
 @pytest.mark.parametrize("mode", ["global", "fit", "fitj"])
 def test_ragged_global_and_fit_batches_in_frames(al, mode):
-    """Ragged global / fit / fit -s batches of reads (l1 <= 208) run on the packed kernels in frames whose work items hold
+    """Ragged global / fit / fit -s batches of reads (l1 <= 304) run on the packed kernels in frames whose work items hold
     reads of one length: 8-lane groups up to 152 bases, 16-lane groups beyond; l2 differs inside an item.  Length mixes
     around every rows-per-lane class edge, a few lengths that occur once (their items are padded with repeats), related and
     unrelated pairs, both alphabets, with and without tracebacks -- score / end cell / start state / ops against the
-    oracle; a batch with one read of 209 bases falls back to the int32 kernel."""
+    oracle; a batch with one read of 305 bases falls back to the int32 kernel."""
     rng = random.Random(4471)
     uj = mode == "fitj"
     m = "fit" if uj else mode
-    for alpha, lens in (("ACGT", [1, 2, 39, 40, 41, 48, 49, 56, 57, 64, 65, 80, 81, 104, 105, 128, 129, 150, 151, 152, 153, 160, 161, 200, 208]), ("ACGTN", [30, 100, 150, 180])):
+    for alpha, lens in (("ACGT", [1, 2, 39, 40, 41, 48, 49, 56, 57, 64, 65, 80, 81, 104, 105, 128, 129, 150, 151, 152, 153, 160, 161, 200, 208, 209, 250, 256, 257, 300, 304]),
+                        ("ACGTN", [30, 100, 150, 180, 250, 290])):
         dna = lambda n: "".join(rng.choice(alpha) for _ in range(n))
         pairs = []
         for k in range(1400):
-            l1 = rng.choice(lens) if k % 4 else rng.randint(1, 208)
+            l1 = rng.choice(lens) if k % 4 else rng.randint(1, 304)
             l2 = rng.randint(max(l1, 2), max(l1, 2) + rng.choice([0, 5, 60, 300]))
             a = dna(l1)
             if k % 2:
@@ -677,7 +679,7 @@ def test_ragged_global_and_fit_batches_in_frames(al, mode):
                     if tb:
                         assert res["ops"][k] == r["ops"], (mode, alpha, sc, k, len(a), len(b))
     al.set_scoring(2, -2, -5, -1, -10, uj, sites)
-    longer = pairs[:200] + [(dna(209), dna(400))]
+    longer = pairs[:200] + [(dna(305), dna(400))]
     res = al.align_batch(m, longer, render=False)
     assert "int32" in al.last_config
     r = O.align(O.MODE_NAMES[m], longer[-1][0], longer[-1][1], 2, -2, -5, -1, -10, uj, sites)

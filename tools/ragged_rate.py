@@ -4,6 +4,8 @@ packed kernels in frames -- against uniform batches of the workload's nominal sh
     local   150 x 150        vs   100..150 x 100..150 and 30..150 x 30..150
     fit -s  150 x 500 (C4)   vs   100..150 x 400..500
     global  150 x 150        vs   100..150 x 100..150
+    local   250 x 250        vs   200..250 x 200..250          global  300 x 300   vs   250..300 x 250..300
+AT_RAGGED_PACKED=0 keeps ragged batches on the int32 kernel (the rate before frames).
 """
 import ctypes as C
 import os
@@ -25,7 +27,11 @@ CASES = [
     ("local", (2, -2, -5, -2, -10), False, [], 150, 150, [("uniform 150x150", 150, 150), ("ragged 100..150 x 100..150", 100, 100), ("ragged 30..150 x 30..150", 30, 30)]),
     ("fit", (2, -2, -5, -1, -10), True, [100, 200, 300, 400], 150, 500, [("uniform 150x500 (C4)", 150, 500), ("ragged 100..150 x 400..500", 100, 400)]),
     ("global", (1, -1, -4, -1, -10), False, [], 150, 150, [("uniform 150x150", 150, 150), ("ragged 100..150 x 100..150", 100, 100)]),
+    ("local", (2, -2, -5, -2, -10), False, [], 250, 250, [("uniform 250x250", 250, 250), ("ragged 200..250 x 200..250", 200, 200)]),
+    ("global", (1, -1, -4, -1, -10), False, [], 300, 300, [("uniform 300x300", 300, 300), ("ragged 250..300 x 250..300", 250, 250)]),
 ]
+if len(sys.argv) > 1:   # e.g. `ragged_rate.py 250 300`: only the cases of those read lengths
+    CASES = [c for c in CASES if str(c[4]) in sys.argv[1:]]
 for mode, sc, uj, sites, L1, L2, rows in CASES:
     al.set_scoring(*sc, uj, sites)
     blob = synth_pairs_blob(0x5EED0002, n, L1, L2).reshape(-1).copy()

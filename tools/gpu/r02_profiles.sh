@@ -36,7 +36,7 @@ find $O/stats $O/stats1 -name "*kernel_stats.csv" -exec cp {} $O/ \; 2>/dev/null
 echo "rocprof done"
 # read-length sweep (driver-style 20 steps) and ragged host-path rates
 : > $O/length_sweep.jsonl
-for L in 36 48 50 64 75 100 125 150 152 200 250 300; do
+for L in 36 48 50 64 75 100 125 150 152 200 250 300 350 416 512 608; do
   timeout -k 10 200 python3 bench.py --l1 $L --l2 $L --pairs $((2250000000 / L / L)) --steps 20 --warmup 5 --no-cpu-baseline >> $O/length_sweep.jsonl 2>> $O/bench.err || true
 done
 timeout -k 10 300 python3 tools/ragged_rate.py > $O/ragged_rate.txt 2>&1 || true

@@ -5,6 +5,7 @@
 	at_sweep16_fn at_pick16_g16_b##b(int kmode, int k, int store, bool tb);        \
 	at_sweep16_fn at_pick16_g32_b##b(int kmode, int k, int store, bool tb);        \
 	at_sweep16_fn at_pick16_g8_b##b(int kmode, int k, int store, bool tb);         \
+	at_sweep16_fn at_pick16_g4_b##b(int kmode, int k, int store, bool tb);         \
 	at_sweep16_fn at_pick16_rag_impl_b##b(int k, int store, bool tb);                \
 	at_sweep16_fn at_pick16_rag8a_b##b(int kmode, int k, int store, bool tb);      \
 	at_sweep16_fn at_pick16_rag8b_b##b(int kmode, int k, int store, bool tb);      \
@@ -18,6 +19,7 @@ AT_DECL(8)
 at_sweep16_fn at_pick16(int kmode, int g, int k, int ts, int store, bool tb, int bits)
 {
 	if (g == 8) return ts != 4 ? nullptr : bits == 8 ? at_pick16_g8_b8(kmode, k, store, tb) : at_pick16_g8_b2(kmode, k, store, tb);
+	if (g == 4) return ts != 4 ? nullptr : bits == 8 ? at_pick16_g4_b8(kmode, k, store, tb) : at_pick16_g4_b2(kmode, k, store, tb);
 	if (g == 32) return ts != 4 ? nullptr : bits == 8 ? at_pick16_g32_b8(kmode, k, store, tb) : at_pick16_g32_b2(kmode, k, store, tb);
 	if (bits == 8) {
 		if (g == 16) return ts == 4 ? at_pick16_g16_b8(kmode, k, store, tb) : nullptr;

@@ -154,7 +154,7 @@ AT_DEV int sat16(int v) { return v < -32768 ? -32768 : (v > 32767 ? 32767 : v); 
 
 /* second __launch_bounds__ argument = waves per SIMD the register allocator must leave room for */
 #ifndef AT_WAVES16
-#define AT_WAVES16(G, K) ((G) == 8 ? ((K) >= 16 ? 2 : (K) >= 10 ? 3 : 1) : ((G) == 16 && (K) >= 16) || ((G) == 32 && (K) >= 10) ? 2 : (G) == 16 && (K) >= 10 ? 3 : 1)
+#define AT_WAVES16(G, K) ((G) == 8 || (G) == 4 ? ((K) >= 16 ? 2 : (K) >= 10 ? 3 : 1) : ((G) == 16 && (K) >= 16) || ((G) == 32 && (K) >= 10) ? 2 : (G) == 16 && (K) >= 10 ? 3 : 1)
 #endif
 
 /* shift up by one lane inside a group of G lanes; lane 0 of each group keeps `old` */
@@ -171,6 +171,11 @@ AT_DEV uint32_t grp_up1(uint32_t old, uint32_t src)
 		/* two groups per DPP row of 16: lane 8 of a row (lane 0 of the second group) keeps its own `old` */
 		const uint32_t v = (uint32_t)__builtin_amdgcn_update_dpp((int)old, (int)src, 0x111 /* row_shr:1 */, 0xf, 0xf, false);
 		return (threadIdx.x & 15) == 8 ? old : v;
+	}
+	else if constexpr (G == 4) {
+		/* four groups per DPP row of 16: lanes 4, 8 and 12 of a row (lane 0 of their groups) keep their own `old` */
+		const uint32_t v = (uint32_t)__builtin_amdgcn_update_dpp((int)old, (int)src, 0x111 /* row_shr:1 */, 0xf, 0xf, false);
+		return (threadIdx.x & 3) == 0 ? old : v;
 	}
 	else return (uint32_t)__builtin_amdgcn_update_dpp((int)old, (int)src, 0x111 /* row_shr:1 */, 0xf, 0xf, false);
 }
@@ -224,7 +229,7 @@ __global__ __launch_bounds__(64, AT_WAVES16(G, K)) void at_sweep16(const Sweep16
 	constexpr int TGL = TB ? OTGL : 0, TGM = TB ? OTGM : 0, TGU = TB ? OTGU : 0;
 	constexpr int PB = HASJ ? 8 : 4;          /* pointer bits per cell and alignment */
 	constexpr int SPW = 16 / PB;              /* steps per pointer word (each half holds its own alignment) */
-	static_assert(G == 64 || G == 32 || G == 16 || G == 8, "group width");
+	static_assert(G == 64 || G == 32 || G == 16 || G == 8 || G == 4, "group width");
 	constexpr int NG = 64 / G;                /* groups per wavefront, 2 alignments each */
 	/* steps per unrolled block.  The 16-lane kernels carry 7..13 rows per lane, so 4 steps (one pointer word) already
 	 * unroll to ~6 KB of code and only one (masked) body is emitted: every launch starts with a cold instruction
@@ -408,7 +413,7 @@ __global__ __launch_bounds__(64, AT_WAVES16(G, K)) void at_sweep16(const Sweep16
 #pragma unroll
 			for (int c = 0; c < NCH; ++c) { best[c] = 0x80008000u; bt[c] = 0; }
 			auto load_bound = [&](int t0, uint32_t &bx, uint32_t &bl) {
-				const int jn = imin(t0 + 1 + (lane & 7), l2);
+				const int jn = imin(t0 + 1 + (lane & (BLK - 1)), l2);   /* lane k of a group: the boundary cell of step k (row_shl<k> brings it to lane 0) */
 				const uint2 v = mem.ld2(a.off_bound + 2 * jn);
 				bx = v.x; bl = v.y;
 			};
@@ -667,6 +672,19 @@ __global__ __launch_bounds__(64, AT_WAVES16(G, K)) void at_sweep16(const Sweep16
 		/* ================= end cells: lane gh receives the result of alignment gh = 2*group + half ================= */
 		int my_sc = 0, my_ci = 0, my_cj = 0, my_st = 2;
 		bool my_ok = true;
+		if constexpr (MODE == K_LOCAL) {
+			/* every group folds its lanes' winners at once, both halves: afterwards each lane of a group holds the group's */
+#pragma unroll
+			for (int h = 0; h < 2; ++h) {
+				int bs = gbs[h], bi = gbi[h], bj = gbj[h];
+				for (int d = G / 2; d >= 1; d >>= 1) {
+					const int ob = __shfl_xor(bs, d), oi = __shfl_xor(bi, d), oj = __shfl_xor(bj, d);
+					const bool take = ob > bs || (ob == bs && (oi < bi || (oi == bi && oj < bj)));
+					if (take) { bs = ob; bi = oi; bj = oj; }
+				}
+				gbs[h] = bs; gbi[h] = bi; gbj[h] = bj;
+			}
+		}
 #pragma unroll 1
 		for (int gh = 0; gh < 2 * NG; ++gh) {
 			const int g = gh >> 1, h = gh & 1;
@@ -674,14 +692,8 @@ __global__ __launch_bounds__(64, AT_WAVES16(G, K)) void at_sweep16(const Sweep16
 			int sc16 = 0, ci = 0, cj = 0, st = 2;
 			bool ok = true;
 			if constexpr (MODE == K_LOCAL) {
-				int bs = gbs[h], bi = gbi[h], bj = gbj[h];
-				for (int d = G / 2; d >= 1; d >>= 1) {
-					const int ob = __shfl_xor(bs, d), oi = __shfl_xor(bi, d), oj = __shfl_xor(bj, d);
-					const bool take = ob > bs || (ob == bs && (oi < bi || (oi == bi && oj < bj)));
-					if (take) { bs = ob; bi = oi; bj = oj; }
-				}
-				sc16 = __builtin_amdgcn_readlane(bs, glane); ci = __builtin_amdgcn_readlane(bi, glane);
-				cj = __builtin_amdgcn_readlane(bj, glane); st = 2;
+				sc16 = __builtin_amdgcn_readlane(h ? gbs[1] : gbs[0], glane); ci = __builtin_amdgcn_readlane(h ? gbi[1] : gbi[0], glane);
+				cj = __builtin_amdgcn_readlane(h ? gbj[1] : gbj[0], glane); st = 2;
 			} else if constexpr (MODE == K_GLOBAL) {
 				const int own = glane + lastlane;
 				int eL, eM, eU;

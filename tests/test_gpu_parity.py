@@ -1115,7 +1115,8 @@ def test_packed_8_lane_groups(al, mode):
     rng = random.Random(808)
     uj = mode == "fitj"
     m = "fit" if uj else mode
-    for l1, l2, alpha, n in ((1, 9, "ACGT", 3), (36, 36, "ACGT", 40), (40, 120, "ACGT", 17), (41, 41, "ACGTN", 33), (48, 48, "ACGT", 20), (49, 60, "ACGT", 17), (56, 70, "ACGT", 16), (57, 57, "ACGT", 31),
+    for l1, l2, alpha, n in ((1, 9, "ACGT", 3), (4, 4, "ACGT", 70), (36, 36, "ACGT", 40), (37, 500, "ACGT", 65), (40, 120, "ACGT", 17), (41, 41, "ACGTN", 33), (48, 48, "ACGT", 20), (49, 60, "ACGT", 17),
+                             (52, 52, "ACGTN", 64), (53, 53, "ACGT", 33), (56, 70, "ACGT", 16), (57, 57, "ACGT", 31),
                              (64, 64, "ACGT", 33), (65, 65, "ACGTN", 18),
                              (80, 80, "ACGT", 48), (81, 150, "ACGTN", 19), (104, 104, "ACGT", 23), (105, 130, "ACGT", 32), (128, 128, "ACGT", 35),
                              (129, 500, "ACGT", 21), (150, 150, "ACGT", 50), (150, 500, "ACGT", 37), (152, 152, "ACGTN", 18), (151, 153, "ACGT", 5)):
@@ -1140,15 +1141,23 @@ def test_packed_8_lane_groups(al, mode):
         sc = (2, -2, -5, -2, -9) if mode != "global" else (1, -2, -4, -1, -9)
         sites = [5, 50, 150, 250]
         al.set_scoring(*sc, uj, sites)
-        for tb in (True, False):
-            res = al.align_batch(m, pairs, traceback=tb, render=False)
-            assert "8x8-lane groups" in al.last_config, (l1, l2, al.last_config)
-            for k, (x, y) in enumerate(pairs):
-                r = O.align(O.MODE_NAMES[m], x, y, *sc, uj, sites)
-                assert (int(res["score"][k]), int(res["end_i"][k]), int(res["end_j"][k]), int(res["state"][k])) == \
-                       (r["score"], r["end_i"], r["end_j"], r["state"]), (mode, l1, l2, k, tb)
-                if tb:
-                    assert res["ops"][k] == r["ops"], (mode, l1, l2, k)
+        want = [O.align(O.MODE_NAMES[m], x, y, *sc, uj, sites) for x, y in pairs]
+        # reads of up to 52 bases run on sixteen groups of 4 lanes (32 alignments per wavefront, 9 / 10 / 13 rows per lane);
+        # AT_GROUP=8 keeps them on the 8-lane groups (5 / 6 / 7 rows per lane)
+        for force8 in ((False, True) if l1 <= 52 else (False,)):
+            for tb in (True, False):
+                if force8:
+                    os.environ["AT_GROUP"] = "8"
+                try:
+                    res = al.align_batch(m, pairs, traceback=tb, render=False)
+                finally:
+                    os.environ.pop("AT_GROUP", None)
+                assert ("16x4-lane groups" if l1 <= 52 and not force8 else "8x8-lane groups") in al.last_config, (l1, l2, al.last_config)
+                for k, r in enumerate(want):
+                    assert (int(res["score"][k]), int(res["end_i"][k]), int(res["end_j"][k]), int(res["state"][k])) == \
+                           (r["score"], r["end_i"], r["end_j"], r["state"]), (mode, l1, l2, k, tb, force8)
+                    if tb:
+                        assert res["ops"][k] == r["ops"], (mode, l1, l2, k, force8)
 
 
 @pytest.mark.parametrize("mode", ["local", "global", "fit", "fitj"])

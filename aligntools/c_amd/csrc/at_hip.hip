@@ -309,7 +309,7 @@ struct Layout16 {
 };
 
 /* Group width: reads of up to 152 bases run as 8 groups of 8 lanes x K rows (16 alignments per wave: 94 % of the
- * lane-steps inside a 150 x 150 matrix, the per-step overhead spread over 19 rows; reads of up to 52 bases: 16 groups of 4
+ * lane-steps inside a 150 x 150 matrix, the per-step overhead spread over 19 rows; reads of up to 76 bases: 16 groups of 4
  * lanes, 32 alignments per wave), up to 208 bases as 4 groups of 16
  * lanes (8 alignments per wave, 85 %; one group of 64 lanes: 59 %) and so do 209..304 bases with 16 / 19 rows per lane,
  * 305..608 bases as 2 groups of 32 lanes (10 .. 19 rows per lane), everything
@@ -327,10 +327,10 @@ static Layout16 layout16_for(bool tb, bool hasj, int l1, int l2, int ts, int for
 	if (overlap) L.k = env_ll("AT_ROWS_PER_LANE", 0) == 4 ? 4 : ((l1 + 1023) / 1024) * (16 * 9 + 45) < ((l1 + 255) / 256) * (4 * 9 + 30) ? 16 : 4;
 	if (force_g == 64) {
 		/* the sliver of a batch behind its whole rounds (align_device): one group of 64 lanes, whatever the read length */
-	} else if (!force_g && (g_forced == 0 || g_forced == 4) && ts == 4 && l1 <= 52) {
-		/* reads of up to 52 bases: sixteen groups of 4 lanes x 9 / 10 / 13 rows, 32 alignments per wave */
+	} else if (!force_g && (g_forced == 0 || g_forced == 4) && ts == 4 && l1 <= 76) {
+		/* reads of up to 76 bases: sixteen groups of 4 lanes x 9 / 10 / 13 / 16 / 19 rows, 32 alignments per wave */
 		L.g = 4;
-		L.k = l1 <= 36 ? 9 : l1 <= 40 ? 10 : 13;
+		L.k = l1 <= 36 ? 9 : l1 <= 40 ? 10 : l1 <= 52 ? 13 : l1 <= 64 ? 16 : 19;
 	} else if (force_g != 16 && (force_g == 8 || g_forced == 0 || g_forced == 8) && ts == 4 && l1 <= 152) {
 		L.g = 8;
 		L.k = l1 <= 40 ? 5 : l1 <= 48 ? 6 : l1 <= 56 ? 7 : l1 <= 64 ? 8 : l1 <= 80 ? 10 : l1 <= 104 ? 13 : l1 <= 128 ? 16 : 19;

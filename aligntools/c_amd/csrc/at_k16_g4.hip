@@ -18,8 +18,10 @@ static at_sweep16_fn f2(int k, bool tb)
 	default: return nullptr;
 	}
 }
+at_sweep16_fn AT_NAME(at_pick16_g4b)(int kmode, int k, int store, bool tb);
 at_sweep16_fn AT_NAME(at_pick16_g4)(int kmode, int k, int store, bool tb)
 {
+	if (k >= 16) return AT_NAME(at_pick16_g4b)(kmode, k, store, tb);
 	if (tb && store != 1) return nullptr;   /* no all-LDS and no all-HBM variant */
 	switch (kmode) {
 	case at::K_GLOBAL: return f2<at::K_GLOBAL>(k, tb);

@@ -117,7 +117,7 @@ int at_align_batch(at_handle *h, int mode, int64_t npairs,
  *              the int32 kernel runs accordingly (3 % slower than with the
  *              promise, not 2.5 times).  A pair that breaks
  *              the promise is not swept: it and the pairs sharing its work item
- *              (at most 16; 32 for reads of up to 52 bases) come back with
+ *              (at most 16; 32 for reads of up to 76 bases) come back with
  *              score INT32_MIN and nops -1.
  */
 int at_align_batch_device(at_handle *h, int mode, int64_t npairs,

@@ -1117,7 +1117,7 @@ def test_packed_8_lane_groups(al, mode):
     m = "fit" if uj else mode
     for l1, l2, alpha, n in ((1, 9, "ACGT", 3), (4, 4, "ACGT", 70), (36, 36, "ACGT", 40), (37, 500, "ACGT", 65), (40, 120, "ACGT", 17), (41, 41, "ACGTN", 33), (48, 48, "ACGT", 20), (49, 60, "ACGT", 17),
                              (52, 52, "ACGTN", 64), (53, 53, "ACGT", 33), (56, 70, "ACGT", 16), (57, 57, "ACGT", 31),
-                             (64, 64, "ACGT", 33), (65, 65, "ACGTN", 18),
+                             (64, 64, "ACGT", 33), (65, 65, "ACGTN", 18), (64, 300, "ACGTN", 70), (76, 76, "ACGT", 64), (75, 90, "ACGT", 31), (77, 77, "ACGT", 33),
                              (80, 80, "ACGT", 48), (81, 150, "ACGTN", 19), (104, 104, "ACGT", 23), (105, 130, "ACGT", 32), (128, 128, "ACGT", 35),
                              (129, 500, "ACGT", 21), (150, 150, "ACGT", 50), (150, 500, "ACGT", 37), (152, 152, "ACGTN", 18), (151, 153, "ACGT", 5)):
         pairs = []
@@ -1142,9 +1142,9 @@ def test_packed_8_lane_groups(al, mode):
         sites = [5, 50, 150, 250]
         al.set_scoring(*sc, uj, sites)
         want = [O.align(O.MODE_NAMES[m], x, y, *sc, uj, sites) for x, y in pairs]
-        # reads of up to 52 bases run on sixteen groups of 4 lanes (32 alignments per wavefront, 9 / 10 / 13 rows per lane);
-        # AT_GROUP=8 keeps them on the 8-lane groups (5 / 6 / 7 rows per lane)
-        for force8 in ((False, True) if l1 <= 52 else (False,)):
+        # reads of up to 76 bases run on sixteen groups of 4 lanes (32 alignments per wavefront, 9 / 10 / 13 / 16 / 19 rows per lane);
+        # AT_GROUP=8 keeps them on the 8-lane groups (5 / 6 / 7 / 8 / 10 rows per lane)
+        for force8 in ((False, True) if l1 <= 76 else (False,)):
             for tb in (True, False):
                 if force8:
                     os.environ["AT_GROUP"] = "8"
@@ -1152,7 +1152,7 @@ def test_packed_8_lane_groups(al, mode):
                     res = al.align_batch(m, pairs, traceback=tb, render=False)
                 finally:
                     os.environ.pop("AT_GROUP", None)
-                assert ("16x4-lane groups" if l1 <= 52 and not force8 else "8x8-lane groups") in al.last_config, (l1, l2, al.last_config)
+                assert ("16x4-lane groups" if l1 <= 76 and not force8 else "8x8-lane groups") in al.last_config, (l1, l2, al.last_config)
                 for k, r in enumerate(want):
                     assert (int(res["score"][k]), int(res["end_i"][k]), int(res["end_j"][k]), int(res["state"][k])) == \
                            (r["score"], r["end_i"], r["end_j"], r["state"]), (mode, l1, l2, k, tb, force8)
@@ -1196,9 +1196,9 @@ def test_sliver_of_a_batch_on_64_lane_groups(al, mode, monkeypatch):
         fresh = [mk() for _ in range(700)]
         base = [mk() for _ in range(2048)]
         for tb in (True, False):
-            al.align_batch(m, probe * 1024, traceback=tb, render=False)    # one full-size call tells the grid of this kernel on this chip
+            al.align_batch(m, probe * 2048, traceback=tb, render=False)    # one full-size call tells the grid of this kernel on this chip
             g = re.search(r"(\d+)x(\d+)-lane groups \((\d+) pairs/wave\).* grid=(\d+)", al.last_config)
-            assert g and int(g.group(2)) in (8, 16), al.last_config
+            assert g and int(g.group(2)) in (4, 8, 16), al.last_config
             per_wave, grid = int(g.group(3)), int(g.group(4))
             n = (grid + 37) * per_wave - 3                              # one round, then 37 work items, the last one not full
             pairs = (base * (n // 2048 + 1))[:n - 700] + fresh

@@ -42,23 +42,37 @@ __device__ __forceinline__ uint32_t render_base(const uint32_t *seq, long long w
 	}
 }
 
-template <int BITS>
+/* W lanes per pair, 64 / W pairs per wavefront side by side.  An alignment of unrelated 150-base reads has a dozen ops, one of
+ * 36-base reads fewer: with one pair per wavefront the kernel is a chain of four dependent loads per pair with most lanes idle
+ * (1.7 M pairs of 36 bases: 0.63 ms, more than half of their sweep); with W = 16 four such chains share a wavefront. */
+template <int BITS, int W>
 __global__ __launch_bounds__(256) void at_render_k(const RenderArgs a)
 {
-	const int lane = threadIdx.x & 63;
+	constexpr int NGR = 64 / W;
+	const int lane = threadIdx.x & 63, g = lane / W, lg = lane % W;
 	const long long wave = (long long)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
 	const long long nwaves = (long long)gridDim.x * (blockDim.x >> 6);
-	const unsigned long long lt = (1ull << lane) - 1ull;
+	const unsigned long long gm = W == 64 ? ~0ull : ((1ull << W) - 1ull) << (W * g);   /* my group's lanes */
+	const unsigned long long lt = ((1ull << lg) - 1ull) << (W * g);                     /* ... below me */
 	int bad = 0;
-	for (long long k = wave; k < a.npairs; k += nwaves) {
-		const int n = a.nops[k];
-		if (n < 0) continue;                                   /* flagged by the sweep kernel already */
-		const long long oo = a.ops_off[k];
-		const long long so = a.str_off ? a.str_off[k] : oo;
-		const long long w1 = a.woff1[k], w2 = a.woff2[k];
-		int i = a.end_i[k], j = a.end_j[k];
-		for (int base = 0; base < n; base += 64) {
-			const int p = base + lane;
+	for (long long kk = wave * NGR; kk < a.npairs; kk += nwaves * NGR) {
+		const long long k = kk + g;
+		const bool valid = k < a.npairs;
+		const int nraw = valid ? a.nops[k] : -1;               /* < 0: flagged by the sweep kernel already (or no pair) */
+		const int n = nraw < 0 ? 0 : nraw;
+		int nmax = n;
+#pragma unroll
+		for (int d = W; d < 64; d <<= 1) nmax = max(nmax, __shfl_xor(nmax, d));
+		long long oo = 0, so = 0, w1 = 0, w2 = 0;
+		int i = 0, j = 0;
+		if (nraw >= 0) {
+			oo = a.ops_off[k];
+			so = a.str_off ? a.str_off[k] : oo;
+			w1 = a.woff1[k]; w2 = a.woff2[k];
+			i = a.end_i[k]; j = a.end_j[k];
+		}
+		for (int base = 0; base < nmax; base += W) {
+			const int p = base + lg;
 			const bool act = p < n;
 			const uint32_t op = act ? a.ops[oo + p] : 0xffu;
 			const bool di = act && op <= 1u;                   /* MID, LOW consume a row    */
@@ -74,10 +88,10 @@ __global__ __launch_bounds__(256) void at_render_k(const RenderArgs a)
 				a.r1[so + (n - 1 - p)] = (uint8_t)c1;
 				a.r2[so + (n - 1 - p)] = (uint8_t)c2;
 			}
-			i -= __popcll(mi);
-			j -= __popcll(mj);
+			i -= __popcll(mi & gm);
+			j -= __popcll(mj & gm);
 		}
-		if (a.nul && lane == 0) { a.r1[so + n] = 0; a.r2[so + n] = 0; }
+		if (a.nul && lg == 0 && nraw >= 0) { a.r1[so + n] = 0; a.r2[so + n] = 0; }
 	}
 	if (__any(bad) && lane == 0) atomicOr(a.bad, 1);
 }

@@ -592,16 +592,15 @@ extern "C" int at_render_batch_device(at_handle *h, int64_t npairs,
 	ra.npairs = npairs; ra.seq = d_seq; ra.woff1 = (const long long *)d_woff1; ra.woff2 = (const long long *)d_woff2;
 	ra.end_i = d_end_i; ra.end_j = d_end_j; ra.ops = d_ops; ra.ops_off = (const long long *)d_ops_off; ra.nops = d_nops;
 	ra.r1 = d_r1; ra.r2 = d_r2; ra.str_off = (const long long *)d_str_off; ra.nul = nul_terminate ? 1 : 0; ra.bad = h->d_rflag;
-	/* four pairs per wavefront, 16 lanes each (AT_RENDER_GROUP=64: one pair per wavefront, the round-1 form) */
-	const bool wide = env_ll("AT_RENDER_GROUP", 16) == 64;
-	const unsigned grid = (unsigned)std::min<int64_t>((npairs + (wide ? 3 : 15)) / (wide ? 4 : 16), 16LL * h->ncu);
-	if (bits == 2) {
-		if (wide) hipLaunchKernelGGL((at::at_render_k<2, 64>), dim3(grid), dim3(256), 0, s, ra);
-		else hipLaunchKernelGGL((at::at_render_k<2, 16>), dim3(grid), dim3(256), 0, s, ra);
-	} else {
-		if (wide) hipLaunchKernelGGL((at::at_render_k<8, 64>), dim3(grid), dim3(256), 0, s, ra);
-		else hipLaunchKernelGGL((at::at_render_k<8, 16>), dim3(grid), dim3(256), 0, s, ra);
-	}
+	/* four pairs per wavefront, 16 lanes each (AT_RENDER_GROUP = 8 / 32 / 64: A/B runs; 64 = one pair per wavefront, the round-1 form) */
+	const long long rw = env_ll("AT_RENDER_GROUP", 16);
+	const int w = rw == 64 ? 64 : rw == 32 ? 32 : rw == 8 ? 8 : 16;
+	const int per_block = 4 * (64 / w);
+	const unsigned grid = (unsigned)std::min<int64_t>((npairs + per_block - 1) / per_block, 16LL * h->ncu);
+#define AT_RENDER(B, W) hipLaunchKernelGGL((at::at_render_k<B, W>), dim3(grid), dim3(256), 0, s, ra)
+	if (bits == 2) { if (w == 64) AT_RENDER(2, 64); else if (w == 32) AT_RENDER(2, 32); else if (w == 8) AT_RENDER(2, 8); else AT_RENDER(2, 16); }
+	else { if (w == 64) AT_RENDER(8, 64); else if (w == 32) AT_RENDER(8, 32); else if (w == 8) AT_RENDER(8, 8); else AT_RENDER(8, 16); }
+#undef AT_RENDER
 	HIP_TRY(h, hipGetLastError());
 	return AT_OK;
 }

@@ -1,6 +1,6 @@
 """Randomised parity campaign: HIP path (through the C ABI) against the oracle restatement on freshly drawn cases --
 modes, scorings (tie-heavy, zero and large penalties), lengths, alphabets, uniform and ragged batches, jump sites,
-with and without tracebacks.  `python tests/fuzz_parity.py [cases] [seed]` on a GPU box; tests/test_fuzz.py runs a
+with and without tracebacks; every fourth batch with tracebacks also through the GPU rendering of the two gapped strings.  `python tests/fuzz_parity.py [cases] [seed]` on a GPU box; tests/test_fuzz.py runs a
 short campaign inside the GPU suite."""
 import os
 import random
@@ -92,6 +92,13 @@ def run(cases, seed, al=None, verbose=True):
                 assert (int(res["end_i"][k]), int(res["end_j"][k]), int(res["state"][k])) == (r["end_i"], r["end_j"], r["state"]), ctx
                 if tb:
                     assert res["ops"][k] == r["ops"], ctx
+        if tb and mode != "edit" and batches % 4 == 0:
+            # the same batch through at_align_batch_strings: the two gapped strings rendered on the GPU (at_render_k) against the
+            # oracle's -- the reference's r1 / r2
+            st = al.align_batch_strings(mode, pairs)
+            for k, (a, b) in enumerate(pairs):
+                r = O.align(O.MODE_NAMES[mode], a, b, *sc, uj, sites)
+                assert (int(st["score"][k]), st["r1"][k], st["r2"][k]) == (r["score"], r["r1"], r["r2"]), (seed, batches, mode, sc, uj, sites, k, a, b, "strings")
         done += len(pairs)
         batches += 1
     if own:

@@ -35,6 +35,7 @@ struct at_handle {
 	uint32_t *d_sitemask = nullptr; size_t sitemask_words = 0; int sitemask_for_l2 = -1; bool sitemask_dirty = true;
 	uint32_t *d_ws = nullptr; size_t ws_bytes = 0;
 	unsigned long long *d_queue = nullptr;
+	int last_span = 0;              /* max_len1 + max_len2 of the handle's latest batch: the rendering kernel's hint for its group width */
 	void *d_in = nullptr; size_t in_bytes = 0;
 	void *d_out = nullptr; size_t out_bytes = 0;
 	void *d_desc = nullptr; size_t desc_bytes = 0;
@@ -593,7 +594,8 @@ extern "C" int at_render_batch_device(at_handle *h, int64_t npairs,
 	ra.end_i = d_end_i; ra.end_j = d_end_j; ra.ops = d_ops; ra.ops_off = (const long long *)d_ops_off; ra.nops = d_nops;
 	ra.r1 = d_r1; ra.r2 = d_r2; ra.str_off = (const long long *)d_str_off; ra.nul = nul_terminate ? 1 : 0; ra.bad = h->d_rflag;
 	/* four pairs per wavefront, 16 lanes each (AT_RENDER_GROUP = 8 / 32 / 64: A/B runs; 64 = one pair per wavefront, the round-1 form) */
-	const long long rw = env_ll("AT_RENDER_GROUP", 16);
+	/* alignments of long pairs are hundreds of ops long: one pair per wavefront again (C3: 2 833 against 2 871 GCUPS with four) */
+	const long long rw = env_ll("AT_RENDER_GROUP", h->last_span >= 1024 ? 64 : 16);
 	const int w = rw == 64 ? 64 : rw == 32 ? 32 : rw == 8 ? 8 : 16;
 	const int per_block = 4 * (64 / w);
 	const unsigned grid = (unsigned)std::min<int64_t>((npairs + per_block - 1) / per_block, 16LL * h->ncu);
@@ -670,6 +672,7 @@ static int align_device(at_handle *h, int mode, int64_t npairs,
 		return fail(h, AT_ERR_RANGE, "scores may exceed the exact range: max|param|=%lld, l1+l2=%lld", maxabs,
 		            (long long)max_len1 + max_len2);
 
+	h->last_span = max_len1 + max_len2;
 	const int kmode = mode == AT_MODE_GLOBAL ? at::K_GLOBAL : mode == AT_MODE_LOCAL ? at::K_LOCAL
 	                : mode == AT_MODE_FIT ? (h->use_jump ? at::K_FITJ : at::K_FIT)
 	                : mode == AT_MODE_OVERLAP ? at::K_OVERLAP : at::K_EDIT;

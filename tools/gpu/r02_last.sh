@@ -14,7 +14,7 @@ echo "sweep done"
 timeout -k 10 300 python3 bench.py --gpus 1 --steps 20 --warmup 5 > $O/c2_driver_style_bench.json 2>> $O/bench.err
 tail -c 400 $O/c2_driver_style_bench.json
 : > $O/fuzz_parity.txt
-for seed in 901 902 903; do
+for seed in 1101 1102; do
   timeout -k 10 150 python3 tests/fuzz_parity.py 100000 $seed 2>&1 | grep -v amdgpu >> $O/fuzz_parity.txt || echo "seed $seed: time limit or failure" >> $O/fuzz_parity.txt
   tail -1 $O/fuzz_parity.txt
 done

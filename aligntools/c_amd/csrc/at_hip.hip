@@ -1193,7 +1193,11 @@ static int align_host_mt(at_handle *h, int mode, int64_t npairs, const uint8_t *
                          int32_t *out_score, int32_t *out_end_i, int32_t *out_end_j, int32_t *out_state,
                          uint8_t *out_ops, const int64_t *ops_off, int32_t *out_nops, char *out_r1, char *out_r2)
 {
-	const long long want = env_ll("AT_HOST_CHUNKS", 3);
+	/* uniform batches: six chunks (100k pairs of C2: 3.37 ms in one piece, 2.49 in 3 chunks, 2.28 in 6); ragged ones, whose chunks are
+	 * sorted into frames one by one: three (fit -s 100..150 x 400..500: 785 GCUPS in 3 chunks, 693 in 6 -- smaller frames) */
+	bool same = len1 && len2;
+	for (int64_t k = 1; same && k < npairs; ++k) same = len1[k] == len1[0] && len2[k] == len2[0];
+	const long long want = env_ll("AT_HOST_CHUNKS", same ? 6 : 3);
 	const long long min_pairs = env_ll("AT_HOST_CHUNK_MIN", 16384);
 	int nchunks = (int)std::max<long long>(1, std::min<long long>(want, 8));
 	if (!h || npairs < 2 * min_pairs || !seq_blob || !off1 || !len1 || !off2 || !len2 || !out_score) nchunks = 1;

@@ -685,49 +685,55 @@ __global__ __launch_bounds__(64, AT_WAVES16(G, K)) void at_sweep16(const Sweep16
 				gbs[h] = bs; gbi[h] = bi; gbj[h] = bj;
 			}
 		}
-#pragma unroll 1
-		for (int gh = 0; gh < 2 * NG; ++gh) {
-			const int g = gh >> 1, h = gh & 1;
-			const int glane = g * G;               /* lane 0 of the group */
+		{
+			/* lane a < 2*NG fetches alignment a's result from its group (a >> 1) and half (a & 1) with lane-indexed reads: one pass for
+			 * all 4 .. 32 alignments of the item instead of a loop over them */
+			const int h = lane & 1;
+			const int glane = (lane >> 1) * G;     /* lane 0 of the group (lanes >= 2*NG read garbage they never use) */
+			const int own = (glane + lastlane) & 63;
 			int sc16 = 0, ci = 0, cj = 0, st = 2;
 			bool ok = true;
+			auto from = [&](uint32_t v, int src) { return (uint32_t)__shfl((int)v, src & 63); };
 			if constexpr (MODE == K_LOCAL) {
-				sc16 = __builtin_amdgcn_readlane(h ? gbs[1] : gbs[0], glane); ci = __builtin_amdgcn_readlane(h ? gbi[1] : gbi[0], glane);
-				cj = __builtin_amdgcn_readlane(h ? gbj[1] : gbj[0], glane); st = 2;
+				/* (every read is executed by all lanes, then selected: a lane-indexed read inside a branch on h would find its
+				 * source lane switched off) */
+				const int s0 = (int)from((uint32_t)gbs[0], glane), s1 = (int)from((uint32_t)gbs[1], glane);
+				const int i0 = (int)from((uint32_t)gbi[0], glane), i1 = (int)from((uint32_t)gbi[1], glane);
+				const int j0 = (int)from((uint32_t)gbj[0], glane), j1 = (int)from((uint32_t)gbj[1], glane);
+				sc16 = h ? s1 : s0; ci = h ? i1 : i0; cj = h ? j1 : j0;
+				st = 2;
 			} else if constexpr (MODE == K_GLOBAL) {
-				const int own = glane + lastlane;
 				int eL, eM, eU;
 				if constexpr (RAG) {
-					eL = half((uint32_t)__builtin_amdgcn_readlane((int)capL, own), h);
-					eM = half((uint32_t)__builtin_amdgcn_readlane((int)capM, own), h);
-					eU = half((uint32_t)__builtin_amdgcn_readlane((int)capU, own), h);
-					cj = __builtin_amdgcn_readlane(h ? l2B : l2A, glane);
+					eL = half(from(capL, own), h);
+					eM = half(from(capM, own), h);
+					eU = half(from(capU, own), h);
+					const int ca = (int)from((uint32_t)l2A, glane), cb = (int)from((uint32_t)l2B, glane);
+					cj = h ? cb : ca;
 				} else {
-					eL = half((uint32_t)__builtin_amdgcn_readlane((int)pick<K>(L_l, rl), own), h);
-					eM = half(psub((uint32_t)__builtin_amdgcn_readlane((int)pick<K>(Mo_l, rl), own), pk2(o16)), h);
-					eU = half((uint32_t)__builtin_amdgcn_readlane((int)pick<K>(U_l, rl), own), h);
+					eL = half(from(pick<K>(L_l, rl), own), h);
+					eM = half(psub(from(pick<K>(Mo_l, rl), own), pk2(o16)), h);
+					eU = half(from(pick<K>(U_l, rl), own), h);
 					cj = l2;
 				}
 				const int x = TB ? imax3(eL, eM, eU) : imax3(eL | OTGL, eM | OTGM, eU | OTGU);   /* max5(L,M,U) first-wins :466 */
 				sc16 = x; st = x & 3; ci = il1;
 			} else if constexpr (OVL) {
-				const int own = glane + lastlane;
-				sc16 = half((uint32_t)__builtin_amdgcn_readlane((int)bestM, own), h);   /* >= 0: column 0 holds 0 (:951-959) */
-				cj = half((uint32_t)__builtin_amdgcn_readlane((int)bestMj, own), h);
+				sc16 = half(from(bestM, own), h);   /* >= 0: column 0 holds 0 (:951-959) */
+				cj = half(from(bestMj, own), h);
 				ci = il1; st = 2;
 				ok = sc16 > a.thresh16;
 			} else {
-				const int own = glane + lastlane;
-				const int bM = half((uint32_t)__builtin_amdgcn_readlane((int)bestM, own), h);
-				const int jM = half((uint32_t)__builtin_amdgcn_readlane((int)bestMj, own), h);
-				const int bL = half((uint32_t)__builtin_amdgcn_readlane((int)bestL, own), h);
-				const int jL = half((uint32_t)__builtin_amdgcn_readlane((int)bestLj, own), h);
+				const int bM = half(from(bestM, own), h);
+				const int jM = half(from(bestMj, own), h);
+				const int bL = half(from(bestL, own), h);
+				const int jL = half(from(bestLj, own), h);
 				ci = il1;
 				if ((bL >> TS) > (bM >> TS) && bL > a.thresh16) { sc16 = bL; st = 3; cj = jL; }
 				else { sc16 = bM; st = 2; cj = jM; }
 				ok = sc16 > a.thresh16;
 			}
-			if (lane == gh) { my_sc = sc16; my_ci = ci; my_cj = cj; my_st = st; my_ok = ok; }
+			my_sc = sc16; my_ci = ci; my_cj = cj; my_st = st; my_ok = ok;
 		}
 		/* ================= results; tracebacks: the 2*NG pointer walks run side by side, one per lane, so their
 		 *                   dependent pointer loads overlap instead of queueing behind each other ================= */

@@ -25,8 +25,8 @@ ST_LOW, ST_MID, ST_UPP = 1, 2, 3
 # every symbol include/aligntools_hip.h declares
 ABI_SYMBOLS = ["at_init", "at_destroy", "at_last_error", "at_set_scoring", "at_align_batch",
                "at_align_batch_device", "at_align_allpairs_device", "at_render_batch_device", "at_compact_ops_device",
-               "at_align_batch_strings", "at_align_allpairs",
-               "at_comm_init", "at_comm_broadcast_scoring", "at_comm_allgather", "at_comm_destroy",
+               "at_align_batch_strings", "at_align_allpairs", "at_align_allpairs_stream",
+               "at_comm_init", "at_comm_broadcast_scoring", "at_comm_allgather", "at_comm_destroy", "at_comm_abi_checked",
                "at_pack_words", "at_pack_batch", "at_render", "at_last_config"]
 
 _i32p = C.POINTER(C.c_int32)
@@ -34,6 +34,8 @@ _i64p = C.POINTER(C.c_int64)
 _u8p = C.POINTER(C.c_uint8)
 _u32p = C.POINTER(C.c_uint32)
 _lib = None
+# at_allpairs_chunk_fn of include/aligntools_hip.h
+ALLPAIRS_CHUNK_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int64, C.c_int64, _i32p, _i32p, _i32p, _i32p)
 
 
 class AlignToolsError(RuntimeError):
@@ -108,6 +110,11 @@ def load_library():
     lib.at_align_allpairs.restype = C.c_int
     lib.at_align_allpairs.argtypes = [C.c_void_p, C.c_int, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_int,
                                       C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+    lib.at_align_allpairs_stream.restype = C.c_int
+    lib.at_align_allpairs_stream.argtypes = [C.c_void_p, C.c_int, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_int64,
+                                             ALLPAIRS_CHUNK_FN, C.c_void_p]
+    lib.at_comm_abi_checked.restype = C.c_int
+    lib.at_comm_abi_checked.argtypes = []
     lib.at_pack_words.restype = C.c_int64
     lib.at_pack_words.argtypes = [C.c_int64, C.c_void_p, C.c_void_p, C.c_int]
     lib.at_pack_batch.restype = C.c_int
@@ -296,6 +303,27 @@ class Aligner:
                                                     1 if want_traceback else 0, d_score, d_end_i,
                                                     d_end_j, d_state, d_ops, d_ops_off, d_nops, stream))
 
+
+    def align_allpairs_stream(self, mode, reads_blob, off, lens, first_pair, npairs, chunk_pairs, on_slice):
+        """All-vs-all scores in slices with bounded memory (at_align_allpairs_stream): reads_blob uint8, off int64, lens int32
+        (numpy); on_slice(first, score, end_i, end_j, state) gets numpy views that are valid during the call only."""
+        if isinstance(mode, str):
+            mode = MODES[mode]
+        err = []
+
+        def cb(_user, first, n, sc, ei, ej, st):
+            try:
+                on_slice(int(first), *(np.ctypeslib.as_array(x, shape=(int(n),)) for x in (sc, ei, ej, st)))
+                return 0
+            except BaseException as ex:   # (an exception must not unwind through the C frames)
+                err.append(ex)
+                return 1
+        fn = ALLPAIRS_CHUNK_FN(cb)
+        rc = self._lib.at_align_allpairs_stream(self._h, mode, len(lens), _ptr(reads_blob), _ptr(off), _ptr(lens), first_pair, npairs,
+                                                chunk_pairs, fn, None)
+        if err:
+            raise err[0]
+        self._check(rc)
 
     def align_allpairs_device(self, mode, nreads, d_seq, bits, d_woff, d_len, max_len, first_pair, npairs, want_traceback,
                               d_score, d_end_i, d_end_j, d_state, d_ops, d_ops_off, d_nops, stream=0):

@@ -21,6 +21,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <exception>
 #include <string>
 #include <vector>
 
@@ -38,6 +39,31 @@ typedef int (*fn_bcast)(const void *, void *, size_t, int, int, void *, hipStrea
 typedef int (*fn_allgather)(const void *, void *, size_t, int, void *, hipStream_t);
 typedef int (*fn_destroy)(void *);
 typedef const char *(*fn_errstr)(int);
+constexpr int kNcclInt8 = 0, kNcclInt32 = 2;   /* ncclDataType_t values passed through the int-typed pointers above */
+
+/* The declarations above are written by hand so that the build needs no RCCL.  Where the installed header exists (this
+ * image: /opt/rocm/include/rccl/rccl.h) the compiler checks them against it: the size of the id passed BY VALUE, the two
+ * enum values, and that every entry point has the argument list assumed here (ncclResult_t is an int-sized enum,
+ * ncclComm_t a pointer: the int / void * spellings above are ABI-identical on x86-64). */
+#if __has_include(<rccl/rccl.h>)
+} /* namespace */
+#include <rccl/rccl.h>
+#include <type_traits>
+namespace {
+#define AT_RCCL_ABI_CHECKED 1
+static_assert(sizeof(ncclUniqueId) == sizeof(uid_t128) && alignof(ncclUniqueId) == alignof(uid_t128), "ncclUniqueId is not 128 opaque bytes");
+static_assert((int)ncclInt8 == kNcclInt8 && (int)ncclInt32 == kNcclInt32, "ncclDataType_t values moved");
+static_assert((int)ncclSuccess == 0, "ncclSuccess is not 0");
+static_assert(sizeof(ncclResult_t) == sizeof(int) && sizeof(ncclDataType_t) == sizeof(int) && sizeof(ncclComm_t) == sizeof(void *), "RCCL scalar types");
+static_assert(std::is_same<decltype(&ncclGetUniqueId), ncclResult_t (*)(ncclUniqueId *)>::value, "ncclGetUniqueId");
+static_assert(std::is_same<decltype(&ncclCommInitRank), ncclResult_t (*)(ncclComm_t *, int, ncclUniqueId, int)>::value, "ncclCommInitRank");
+static_assert(std::is_same<decltype(&ncclBroadcast), ncclResult_t (*)(const void *, void *, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t)>::value, "ncclBroadcast");
+static_assert(std::is_same<decltype(&ncclAllGather), ncclResult_t (*)(const void *, void *, size_t, ncclDataType_t, ncclComm_t, hipStream_t)>::value, "ncclAllGather");
+static_assert(std::is_same<decltype(&ncclCommDestroy), ncclResult_t (*)(ncclComm_t)>::value, "ncclCommDestroy");
+static_assert(std::is_same<decltype(&ncclGetErrorString), const char *(*)(ncclResult_t)>::value, "ncclGetErrorString");
+#else
+#define AT_RCCL_ABI_CHECKED 0
+#endif
 
 struct Comm {
 	int rank = 0, world = 1;
@@ -57,6 +83,7 @@ bool wait_for_file(const std::string &path, std::vector<char> &data, double time
 		if (f) {
 			fseek(f, 0, SEEK_END);
 			const long n = ftell(f);
+			if (n < 0) { fclose(f); return false; }
 			fseek(f, 0, SEEK_SET);
 			data.resize((size_t)n);
 			const size_t got = n ? fread(data.data(), 1, (size_t)n, f) : 0;
@@ -110,7 +137,7 @@ int allgather_fixed(at_handle *h, Comm *c, const void *mine, size_t n, void *all
 	if (rc) return rc;
 	char *d_send = (char *)c->d_buf, *d_recv = d_send + pad;
 	if (hipMemcpyAsync(d_send, mine, n, hipMemcpyHostToDevice, c->stream) != hipSuccess) return at_comm_fail(h, AT_ERR_NODEVICE, "at_comm: upload failed");
-	const int e = c->allgather(d_send, d_recv, pad, /* ncclInt8 */ 0, c->comm, c->stream);
+	const int e = c->allgather(d_send, d_recv, pad, kNcclInt8, c->comm, c->stream);
 	if (e) return at_comm_fail(h, AT_ERR_NODEVICE, c->errstr ? c->errstr(e) : "ncclAllGather failed");
 	std::vector<char> host(pad * (size_t)c->world);
 	if (hipMemcpyAsync(host.data(), d_recv, host.size(), hipMemcpyDeviceToHost, c->stream) != hipSuccess || hipStreamSynchronize(c->stream) != hipSuccess)
@@ -121,9 +148,10 @@ int allgather_fixed(at_handle *h, Comm *c, const void *mine, size_t n, void *all
 
 } /* namespace */
 
-extern "C" int at_comm_init(at_handle *h, int rank, int world, const char *dir)
+static int comm_init(at_handle *h, int rank, int world, const char *dir)
 {
 	if (!h || world < 1 || rank < 0 || rank >= world || !dir) return at_comm_fail(h, AT_ERR_ARG, "at_comm_init: bad rank / world / directory");
+	if (*at_comm_slot(h)) return at_comm_fail(h, AT_ERR_ARG, "at_comm_init: this handle already has a communicator (at_comm_destroy first)");
 	Comm *c = new Comm();
 	c->rank = rank; c->world = world; c->dir = dir;
 	const char *mode = getenv("AT_COMM");
@@ -169,7 +197,7 @@ extern "C" int at_comm_init(at_handle *h, int rank, int world, const char *dir)
 
 /* rank 0's scoring block (m, u, o, e, j, use_jump, sites) becomes every rank's: two broadcasts, the fixed part with the number
  * of sites first, then exactly that many sites */
-extern "C" int at_comm_broadcast_scoring(at_handle *h)
+static int comm_broadcast_scoring(at_handle *h)
 {
 	Comm *c = h ? (Comm *)*at_comm_slot(h) : nullptr;
 	if (!c) return at_comm_fail(h, AT_ERR_ARG, "at_comm_broadcast_scoring: no communicator");
@@ -190,22 +218,24 @@ extern "C" int at_comm_broadcast_scoring(at_handle *h)
 				std::vector<char> d;
 				if (!wait_for_file(c->dir + name, d, 600.0) || d.size() < 32) return at_comm_fail(h, AT_ERR_ARG, "at_comm(files): no scoring block from rank 0");
 				memcpy(v, d.data(), 32);
+				if (v[6] < 0 || d.size() < 32 + (size_t)v[6] * 4) return at_comm_fail(h, AT_ERR_ARG, "at_comm(files): truncated scoring block");
 				st.assign((const int *)(d.data() + 32), (const int *)(d.data() + 32) + v[6]);
 			}
 		} else {
 			int rc = dev_buf(h, c, 64);
 			if (rc) return rc;
 			if (hipMemcpyAsync(c->d_buf, v, 32, hipMemcpyHostToDevice, c->stream) != hipSuccess) return at_comm_fail(h, AT_ERR_NODEVICE, "at_comm: upload failed");
-			int e = c->bcast(c->d_buf, c->d_buf, 8, /* ncclInt32 */ 2, 0, c->comm, c->stream);
+			int e = c->bcast(c->d_buf, c->d_buf, 8, kNcclInt32, 0, c->comm, c->stream);
 			if (e) return at_comm_fail(h, AT_ERR_NODEVICE, c->errstr ? c->errstr(e) : "ncclBroadcast failed");
 			if (hipMemcpyAsync(v, c->d_buf, 32, hipMemcpyDeviceToHost, c->stream) != hipSuccess || hipStreamSynchronize(c->stream) != hipSuccess)
 				return at_comm_fail(h, AT_ERR_NODEVICE, "at_comm: download failed");
+			if (v[6] < 0) return at_comm_fail(h, AT_ERR_ARG, "at_comm: negative site count in the scoring block");
 			if (v[6] > 0) {
 				st.resize((size_t)v[6]);
 				rc = dev_buf(h, c, (size_t)v[6] * 4);
 				if (rc) return rc;
 				if (hipMemcpyAsync(c->d_buf, st.data(), (size_t)v[6] * 4, hipMemcpyHostToDevice, c->stream) != hipSuccess) return at_comm_fail(h, AT_ERR_NODEVICE, "at_comm: upload failed");
-				e = c->bcast(c->d_buf, c->d_buf, (size_t)v[6], 2, 0, c->comm, c->stream);
+				e = c->bcast(c->d_buf, c->d_buf, (size_t)v[6], kNcclInt32, 0, c->comm, c->stream);
 				if (e) return at_comm_fail(h, AT_ERR_NODEVICE, c->errstr ? c->errstr(e) : "ncclBroadcast failed");
 				if (hipMemcpyAsync(st.data(), c->d_buf, (size_t)v[6] * 4, hipMemcpyDeviceToHost, c->stream) != hipSuccess || hipStreamSynchronize(c->stream) != hipSuccess)
 					return at_comm_fail(h, AT_ERR_NODEVICE, "at_comm: download failed");
@@ -217,7 +247,7 @@ extern "C" int at_comm_broadcast_scoring(at_handle *h)
 
 /* gather with a different size per rank (sizes first, then one payload padded to the largest): `all` receives the parts
  * back to back in rank order, bytes_of_rank[r] (written by the call) says how long each is */
-extern "C" int at_comm_allgather(at_handle *h, const void *mine, int64_t mine_bytes, void *all, int64_t all_cap, int64_t *bytes_of_rank)
+static int comm_allgather(at_handle *h, const void *mine, int64_t mine_bytes, void *all, int64_t all_cap, int64_t *bytes_of_rank)
 {
 	Comm *c = h ? (Comm *)*at_comm_slot(h) : nullptr;
 	if (!c || mine_bytes < 0 || !bytes_of_rank || (mine_bytes && !mine)) return at_comm_fail(h, AT_ERR_ARG, "at_comm_allgather: bad argument");
@@ -235,6 +265,19 @@ extern "C" int at_comm_allgather(at_handle *h, const void *mine, int64_t mine_by
 	for (int r = 0; r < c->world; ++r) { memcpy((char *)all + o, recv.data() + (size_t)r * (size_t)mx, (size_t)bytes_of_rank[r]); o += bytes_of_rank[r]; }
 	return AT_OK;
 }
+
+/* the C ABI: no C++ exception (std::bad_alloc of a staging vector ...) leaves the library */
+#define AT_COMM_GUARD(call)                                                                          \
+	try { return call; }                                                                             \
+	catch (const std::exception &ex) { return at_comm_fail(h, AT_ERR_NOMEM, ex.what()); }           \
+	catch (...) { return at_comm_fail(h, AT_ERR_NOMEM, "at_comm: unknown C++ exception"); }
+extern "C" int at_comm_init(at_handle *h, int rank, int world, const char *dir) { AT_COMM_GUARD(comm_init(h, rank, world, dir)) }
+extern "C" int at_comm_broadcast_scoring(at_handle *h) { AT_COMM_GUARD(comm_broadcast_scoring(h)) }
+extern "C" int at_comm_allgather(at_handle *h, const void *mine, int64_t mine_bytes, void *all, int64_t all_cap, int64_t *bytes_of_rank)
+{
+	AT_COMM_GUARD(comm_allgather(h, mine, mine_bytes, all, all_cap, bytes_of_rank))
+}
+extern "C" int at_comm_abi_checked(void) { return AT_RCCL_ABI_CHECKED; }   /* 1: built against the installed rccl.h (static_asserts above) */
 
 extern "C" void at_comm_destroy(at_handle *h)
 {

@@ -43,6 +43,10 @@ struct at_handle {
 	void *d_str = nullptr; size_t str_bytes = 0;
 	void *d_scan = nullptr; size_t scan_bytes = 0;
 	int *d_rflag = nullptr;         /* at_render_k's "op list walks off its sequences" flag */
+	/* all-vs-all in slices: a copy stream, pinned result buffers (two sets, used in turn) and their events */
+	hipStream_t copy_stream = nullptr;
+	void *h_pin = nullptr; size_t pin_bytes = 0;
+	hipEvent_t ev_sweep[2] = {nullptr, nullptr}, ev_copy[2] = {nullptr, nullptr};
 	std::vector<at_handle *> kids;  /* helper handles of the host entry: chunks of one batch in flight side by side */
 	void *comm = nullptr;           /* multi-process batches: the communicator (at_comm.hip) */
 	char err[512] = {0};
@@ -137,6 +141,12 @@ extern "C" void at_destroy(at_handle *h)
 	if (h->d_str) (void)hipFree(h->d_str);
 	if (h->d_scan) (void)hipFree(h->d_scan);
 	if (h->d_rflag) (void)hipFree(h->d_rflag);
+	if (h->h_pin) (void)hipHostFree(h->h_pin);
+	for (int q = 0; q < 2; ++q) {
+		if (h->ev_sweep[q]) (void)hipEventDestroy(h->ev_sweep[q]);
+		if (h->ev_copy[q]) (void)hipEventDestroy(h->ev_copy[q]);
+	}
+	if (h->copy_stream) (void)hipStreamDestroy(h->copy_stream);
 	if (h->stream) (void)hipStreamDestroy(h->stream);
 	delete h;
 }
@@ -1246,29 +1256,26 @@ static int align_host_mt(at_handle *h, int mode, int64_t npairs, const uint8_t *
 	return AT_OK;
 }
 
-/* all-vs-all over one read set held in HOST memory: the reads go up once, are packed once, and pairs
- * [first_pair, first_pair + npairs) of the strict upper triangle are enumerated on the GPU (at_align_allpairs_device) */
-extern "C" int at_align_allpairs(at_handle *h, int mode, int64_t nreads, const uint8_t *seq_blob,
-                                 const int64_t *off, const int32_t *len, int64_t first_pair, int64_t npairs, int want_traceback,
-                                 int32_t *out_score, int32_t *out_end_i, int32_t *out_end_j, int32_t *out_state,
-                                 uint8_t *out_ops, const int64_t *ops_off, int32_t *out_nops)
+/* ---- all-vs-all over one read set held in HOST memory ----
+ * The reads go up once and are packed once (upload_reads); pairs of the strict upper triangle are enumerated on the GPU
+ * (at_align_allpairs_device).  The triangle is swept in SLICES of at most `chunk` pairs, so device and host memory are
+ * bounded by the slice, not by the 1.25e9 pairs of C5: scores and end cells of slice c come down on a copy stream and are
+ * handed to the caller while the sweep of slice c + 1 runs. */
+struct ReadSet {
+	uint32_t *d_words = nullptr;
+	int64_t *d_swoff = nullptr;
+	int32_t *d_len = nullptr;
+	int bits = 2, maxlen = 0;
+};
+
+static int upload_reads(at_handle *h, int mode, int64_t nreads, const uint8_t *seq_blob, const int64_t *off, const int32_t *len, ReadSet *rs)
 {
-	if (!h) return fail(nullptr, AT_ERR_ARG, "at_align_allpairs: NULL handle");
-	if (mode < AT_MODE_GLOBAL || mode > AT_MODE_EDIT) return fail(h, AT_ERR_ARG, "unknown mode %d", mode);
-	if (nreads < 2 || first_pair < 0 || npairs < 0 || first_pair + npairs > nreads * (nreads - 1) / 2)
-		return fail(h, AT_ERR_ARG, "all-vs-all: pair range [%lld, +%lld) outside the %lld*(%lld-1)/2 ordered pairs",
-		            (long long)first_pair, (long long)npairs, (long long)nreads, (long long)nreads);
-	if (npairs == 0) return AT_OK;
-	if (!seq_blob || !off || !len || !out_score) return fail(h, AT_ERR_ARG, "NULL argument");
-	const bool tb = want_traceback && mode != AT_MODE_EDIT;
-	if (tb && (!out_ops || !ops_off || !out_nops)) return fail(h, AT_ERR_ARG, "traceback wanted but ops buffers are NULL");
 	int maxlen = 0;
 	int64_t blob_lo = INT64_MAX, blob_bytes = 0, nwords2 = 0, nwords8 = 0;
 	std::vector<int64_t> soff((size_t)nreads), swoff2((size_t)nreads), swoff8((size_t)nreads);
 	for (int64_t k = 0; k < nreads; ++k) {
 		if (len[k] < 0 || off[k] < 0) return fail(h, AT_ERR_ARG, "read %lld: negative length or offset", (long long)k);
 		if ((mode == AT_MODE_LOCAL || mode == AT_MODE_OVERLAP) && len[k] < 1) return fail(h, AT_ERR_DOMAIN, "read %lld: empty", (long long)k);
-		if (mode == AT_MODE_FIT) return fail(h, AT_ERR_ARG, "all-vs-all: fit needs ordered lengths (l1 <= l2); use the pair list entry");
 		maxlen = std::max(maxlen, len[k]);
 		blob_lo = std::min(blob_lo, off[k]);
 	}
@@ -1278,33 +1285,22 @@ extern "C" int at_align_allpairs(at_handle *h, int mode, int64_t nreads, const u
 		swoff8[(size_t)k] = nwords8; nwords8 += (len[k] + 3) / 4 + 1;
 		blob_bytes = std::max<int64_t>(blob_bytes, soff[(size_t)k] + len[k]);
 	}
-	int64_t ops_total = 0, ops_lo = 0, slots_total = 0;
-	std::vector<int64_t> opsr;
-	if (tb) {
-		ops_lo = INT64_MAX;
-		for (int64_t p = 0; p < npairs; ++p) { if (ops_off[p] < 0) return fail(h, AT_ERR_ARG, "pair %lld: negative ops offset", (long long)p); ops_lo = std::min(ops_lo, ops_off[p]); }
-		opsr.resize((size_t)npairs);
-		for (int64_t p = 0; p < npairs; ++p) { opsr[(size_t)p] = ops_off[p] - ops_lo; ops_total = std::max<int64_t>(ops_total, opsr[(size_t)p] + 2LL * maxlen); }
-		slots_total = npairs * 2LL * maxlen;
-	}
 	HIP_TRY(h, hipSetDevice(h->device));
 	auto al = [](size_t x) { return (x + 255) & ~(size_t)255; };
 	const size_t b_words = al((size_t)(std::max(nwords2, nwords8) + 4) * 4), b_off = al((size_t)nreads * 8), b_len = al((size_t)nreads * 4);
-	const size_t b_opsoff = al((size_t)npairs * 8), b_blob = al((size_t)blob_bytes + 16);
-	int rc = grow(h, &h->d_in, &h->in_bytes, b_words + 2 * b_off + b_len + 256 + b_opsoff + b_blob);
+	const size_t b_blob = al((size_t)blob_bytes + 16);
+	int rc = grow(h, &h->d_in, &h->in_bytes, b_words + 2 * b_off + b_len + 256 + b_blob);
 	if (rc) return rc;
 	char *din = (char *)h->d_in;
 	uint32_t *d_words = (uint32_t *)din;
 	int64_t *d_soff = (int64_t *)(din + b_words), *d_swoff = (int64_t *)(din + b_words + b_off);
 	int32_t *d_len = (int32_t *)(din + b_words + 2 * b_off);
 	int *d_flag = (int *)(din + b_words + 2 * b_off + b_len);
-	int64_t *d_opsoff = (int64_t *)(din + b_words + 2 * b_off + b_len + 256);
-	uint8_t *d_blob = (uint8_t *)(din + b_words + 2 * b_off + b_len + 256 + b_opsoff);
+	uint8_t *d_blob = (uint8_t *)(din + b_words + 2 * b_off + b_len + 256);
 	hipStream_t s = h->stream;
 	HIP_TRY(h, hipMemcpyAsync(d_blob, seq_blob + blob_lo, (size_t)blob_bytes, hipMemcpyHostToDevice, s));
 	HIP_TRY(h, hipMemcpyAsync(d_soff, soff.data(), (size_t)nreads * 8, hipMemcpyHostToDevice, s));
 	HIP_TRY(h, hipMemcpyAsync(d_len, len, (size_t)nreads * 4, hipMemcpyHostToDevice, s));
-	if (tb) HIP_TRY(h, hipMemcpyAsync(d_opsoff, opsr.data(), (size_t)npairs * 8, hipMemcpyHostToDevice, s));
 	at::PackArgs pa;
 	pa.nseq = nreads; pa.blob = d_blob; pa.off = (const long long *)d_soff; pa.len = d_len;
 	pa.woff = (const long long *)d_swoff; pa.words = d_words; pa.not_acgt = d_flag;
@@ -1324,43 +1320,189 @@ extern "C" int at_align_allpairs(at_handle *h, int mode, int64_t nreads, const u
 	}
 	HIP_TRY(h, hipGetLastError());
 	HIP_TRY(h, hipStreamSynchronize(s));   /* swoff* are stack-lifetime vectors */
+	rs->d_words = d_words; rs->d_swoff = d_swoff; rs->d_len = d_len; rs->bits = bits; rs->maxlen = maxlen;
+	return AT_OK;
+}
+
+static int check_allpairs_args(at_handle *h, const char *who, int mode, int64_t nreads, int64_t first_pair, int64_t npairs)
+{
+	if (!h) return fail(nullptr, AT_ERR_ARG, "%s: NULL handle", who);
+	if (mode < AT_MODE_GLOBAL || mode > AT_MODE_EDIT) return fail(h, AT_ERR_ARG, "unknown mode %d", mode);
+	if (mode == AT_MODE_FIT) return fail(h, AT_ERR_ARG, "all-vs-all: fit needs ordered lengths (l1 <= l2); use the pair list entry");
+	if (nreads < 2 || nreads >= (1LL << 31) || first_pair < 0 || npairs < 0 || first_pair + npairs > nreads * (nreads - 1) / 2)
+		return fail(h, AT_ERR_ARG, "all-vs-all: pair range [%lld, +%lld) outside the %lld*(%lld-1)/2 ordered pairs",
+		            (long long)first_pair, (long long)npairs, (long long)nreads, (long long)nreads);
+	return AT_OK;
+}
+
+/* scores + end cells of pairs [first_pair, first_pair + npairs) in slices; fn(user, first pair of the slice, pairs, score, end_i,
+ * end_j, state) sees every slice once, in order, on the calling thread */
+static int allpairs_scores(at_handle *h, int mode, int64_t nreads, const ReadSet &rs, int64_t first_pair, int64_t npairs,
+                           int64_t chunk, at_allpairs_chunk_fn fn, void *user)
+{
+	if (chunk <= 0) chunk = env_ll("AT_ALLPAIRS_CHUNK", 4LL << 20);
+	chunk = std::max<int64_t>(1, std::min<int64_t>(chunk, std::min<int64_t>(npairs, 1LL << 28)));
+	auto al = [](size_t x) { return (x + 255) & ~(size_t)255; };
+	const size_t b_res = al((size_t)chunk * 4);
+	int rc = grow(h, &h->d_out, &h->out_bytes, 2 * 4 * b_res);
+	if (rc) return rc;
+	if (h->pin_bytes < 2 * 4 * b_res) {
+		if (h->h_pin) { (void)hipHostFree(h->h_pin); h->h_pin = nullptr; h->pin_bytes = 0; }
+		if (hipHostMalloc(&h->h_pin, 2 * 4 * b_res, hipHostMallocDefault) != hipSuccess)
+			return fail(h, AT_ERR_NOMEM, "hipHostMalloc(%zu) for the result slices failed", 2 * 4 * b_res);
+		h->pin_bytes = 2 * 4 * b_res;
+	}
+	if (!h->copy_stream) HIP_TRY(h, hipStreamCreateWithFlags(&h->copy_stream, hipStreamNonBlocking));
+	for (int q = 0; q < 2; ++q) {
+		if (!h->ev_sweep[q]) HIP_TRY(h, hipEventCreateWithFlags(&h->ev_sweep[q], hipEventDisableTiming));
+		if (!h->ev_copy[q]) HIP_TRY(h, hipEventCreateWithFlags(&h->ev_copy[q], hipEventDisableTiming));
+	}
+	hipStream_t s = h->stream, cs = h->copy_stream;
+	const int64_t nchunks = (npairs + chunk - 1) / chunk;
+	auto dres = [&](int q, int a) { return (int32_t *)((char *)h->d_out + ((size_t)q * 4 + (size_t)a) * b_res); };
+	auto hres = [&](int q, int a) { return (int32_t *)((char *)h->h_pin + ((size_t)q * 4 + (size_t)a) * b_res); };
+	auto deliver = [&](int64_t c) -> int {
+		const int q = (int)(c & 1);
+		const int64_t lo = c * chunk, n = std::min(chunk, npairs - lo);
+		HIP_TRY(h, hipEventSynchronize(h->ev_copy[q]));
+		const int32_t *sc = hres(q, 0);
+		for (int64_t p = 0; p < n; ++p)
+			if (sc[p] == INT32_MIN)
+				return fail(h, AT_ERR_DOMAIN, "pair %lld: input outside the domain on which the reference is defined", (long long)(first_pair + lo + p));
+		if (fn && fn(user, first_pair + lo, n, sc, hres(q, 1), hres(q, 2), hres(q, 3)) != 0)
+			return fail(h, AT_ERR_ARG, "all-vs-all: the caller's slice callback asked to stop at pair %lld", (long long)(first_pair + lo));
+		return AT_OK;
+	};
+	std::string cfg0;
+	for (int64_t c = 0; c < nchunks; ++c) {
+		const int q = (int)(c & 1);
+		const int64_t lo = c * chunk, n = std::min(chunk, npairs - lo);
+		/* (slice c - 2, the last user of buffer set q, was delivered before slice c - 1 was queued) */
+		rc = align_device(h, mode, n, rs.d_words, rs.bits, rs.d_swoff, rs.d_len, rs.d_swoff, rs.d_len, rs.maxlen, rs.maxlen, 0, 0,
+		                  dres(q, 0), dres(q, 1), dres(q, 2), dres(q, 3), nullptr, nullptr, nullptr, s, nreads, first_pair + lo);
+		if (rc) { (void)hipDeviceSynchronize(); return rc; }
+		if (c == 0) cfg0 = h->cfg;
+		HIP_TRY(h, hipEventRecord(h->ev_sweep[q], s));
+		HIP_TRY(h, hipStreamWaitEvent(cs, h->ev_sweep[q], 0));
+		for (int a = 0; a < 4; ++a) HIP_TRY(h, hipMemcpyAsync(hres(q, a), dres(q, a), (size_t)n * 4, hipMemcpyDeviceToHost, cs));
+		HIP_TRY(h, hipEventRecord(h->ev_copy[q], cs));
+		if (c >= 1) {
+			rc = deliver(c - 1);
+			if (rc) { (void)hipDeviceSynchronize(); return rc; }
+		}
+	}
+	rc = deliver(nchunks - 1);
+	if (rc) return rc;
+	snprintf(h->cfg, sizeof h->cfg, "%.260s, %lld slices of <= %lld pairs", cfg0.c_str(), (long long)nchunks, (long long)chunk);
+	return AT_OK;
+}
+
+extern "C" int at_align_allpairs_stream(at_handle *h, int mode, int64_t nreads, const uint8_t *seq_blob,
+                                        const int64_t *off, const int32_t *len, int64_t first_pair, int64_t npairs,
+                                        int64_t chunk_pairs, at_allpairs_chunk_fn fn, void *user)
+{
+	int rc = check_allpairs_args(h, "at_align_allpairs_stream", mode, nreads, first_pair, npairs);
+	if (rc) return rc;
+	if (npairs == 0) return AT_OK;
+	if (!seq_blob || !off || !len || !fn) return fail(h, AT_ERR_ARG, "NULL argument");
+	ReadSet rs;
+	rc = upload_reads(h, mode, nreads, seq_blob, off, len, &rs);
+	if (rc) return rc;
+	return allpairs_scores(h, mode, nreads, rs, first_pair, npairs, chunk_pairs, fn, user);
+}
+
+namespace {
+struct CopyOut { int64_t first; int32_t *score, *end_i, *end_j, *state; };
+int copy_out_slice(void *user, int64_t first, int64_t n, const int32_t *sc, const int32_t *ei, const int32_t *ej, const int32_t *st)
+{
+	const CopyOut *o = (const CopyOut *)user;
+	const size_t at = (size_t)(first - o->first), nb = (size_t)n * 4;
+	memcpy(o->score + at, sc, nb);
+	if (o->end_i) memcpy(o->end_i + at, ei, nb);
+	if (o->end_j) memcpy(o->end_j + at, ej, nb);
+	if (o->state) memcpy(o->state + at, st, nb);
+	return 0;
+}
+}
+
+/* one slice of the triangle WITH tracebacks: ops of pair p go to the caller's slot ops_off[p - first_pair] */
+static int allpairs_tb_slice(at_handle *h, int mode, int64_t nreads, const ReadSet &rs, int64_t first_pair, int64_t npairs,
+                             int32_t *out_score, int32_t *out_end_i, int32_t *out_end_j, int32_t *out_state,
+                             uint8_t *out_ops, const int64_t *ops_off, int32_t *out_nops)
+{
+	const int maxlen = rs.maxlen;
+	int64_t ops_total = 0, ops_lo = INT64_MAX;
+	for (int64_t p = 0; p < npairs; ++p) { if (ops_off[p] < 0) return fail(h, AT_ERR_ARG, "pair %lld: negative ops offset", (long long)(first_pair + p)); ops_lo = std::min(ops_lo, ops_off[p]); }
+	std::vector<int64_t> opsr((size_t)npairs);
+	for (int64_t p = 0; p < npairs; ++p) { opsr[(size_t)p] = ops_off[p] - ops_lo; ops_total = std::max<int64_t>(ops_total, opsr[(size_t)p] + 2LL * maxlen); }
+	const int64_t slots_total = npairs * 2LL * maxlen;
+	auto al = [](size_t x) { return (x + 255) & ~(size_t)255; };
+	int rc = grow(h, &h->d_desc, &h->desc_bytes, al((size_t)npairs * 8));
+	if (rc) return rc;
+	int64_t *d_opsoff = (int64_t *)h->d_desc;
+	hipStream_t s = h->stream;
+	HIP_TRY(h, hipMemcpyAsync(d_opsoff, opsr.data(), (size_t)npairs * 8, hipMemcpyHostToDevice, s));
 	const size_t b_res = al((size_t)npairs * 4), b_ops = al((size_t)ops_total + 64), b_pfx = al((size_t)(npairs + 1) * 8);
-	rc = grow(h, &h->d_out, &h->out_bytes, 5 * b_res + b_ops + (tb ? b_pfx : 0));
+	rc = grow(h, &h->d_out, &h->out_bytes, 5 * b_res + b_ops + b_pfx);
 	if (rc) return rc;
 	char *dout = (char *)h->d_out;
 	int32_t *d_score = (int32_t *)dout, *d_ei = (int32_t *)(dout + b_res), *d_ej = (int32_t *)(dout + 2 * b_res);
 	int32_t *d_st = (int32_t *)(dout + 3 * b_res), *d_nops = (int32_t *)(dout + 4 * b_res);
 	uint8_t *d_ops = (uint8_t *)(dout + 5 * b_res);
 	int64_t *d_poff = (int64_t *)(dout + 5 * b_res + b_ops);
-	rc = align_device(h, mode, npairs, d_words, bits, d_swoff, d_len, d_swoff, d_len, maxlen, maxlen, 0, tb ? 1 : 0, d_score, d_ei, d_ej, d_st,
-	                  tb ? d_ops : nullptr, tb ? d_opsoff : nullptr, tb ? d_nops : nullptr, s, nreads, first_pair);
+	rc = align_device(h, mode, npairs, rs.d_words, rs.bits, rs.d_swoff, rs.d_len, rs.d_swoff, rs.d_len, maxlen, maxlen, 0, 1, d_score, d_ei, d_ej, d_st,
+	                  d_ops, d_opsoff, d_nops, s, nreads, first_pair);
 	if (rc) return rc;
 	HIP_TRY(h, hipMemcpyAsync(out_score, d_score, (size_t)npairs * 4, hipMemcpyDeviceToHost, s));
 	if (out_end_i) HIP_TRY(h, hipMemcpyAsync(out_end_i, d_ei, (size_t)npairs * 4, hipMemcpyDeviceToHost, s));
 	if (out_end_j) HIP_TRY(h, hipMemcpyAsync(out_end_j, d_ej, (size_t)npairs * 4, hipMemcpyDeviceToHost, s));
 	if (out_state) HIP_TRY(h, hipMemcpyAsync(out_state, d_st, (size_t)npairs * 4, hipMemcpyDeviceToHost, s));
-	std::vector<int64_t> h_poff;
-	if (tb) {
-		HIP_TRY(h, hipMemcpyAsync(out_nops, d_nops, (size_t)npairs * 4, hipMemcpyDeviceToHost, s));
-		rc = grow(h, &h->d_str, &h->str_bytes, al((size_t)slots_total + 64));
-		if (rc) return rc;
-		rc = at_compact_ops_device(h, npairs, d_ops, d_opsoff, d_nops, (uint8_t *)h->d_str, slots_total, d_poff, s);
-		if (rc) return rc;
-		h_poff.resize((size_t)npairs + 1);
-		HIP_TRY(h, hipMemcpyAsync(h_poff.data(), d_poff, (size_t)(npairs + 1) * 8, hipMemcpyDeviceToHost, s));
-	}
+	HIP_TRY(h, hipMemcpyAsync(out_nops, d_nops, (size_t)npairs * 4, hipMemcpyDeviceToHost, s));
+	rc = grow(h, &h->d_str, &h->str_bytes, al((size_t)slots_total + 64));
+	if (rc) return rc;
+	rc = at_compact_ops_device(h, npairs, d_ops, d_opsoff, d_nops, (uint8_t *)h->d_str, slots_total, d_poff, s);
+	if (rc) return rc;
+	std::vector<int64_t> h_poff((size_t)npairs + 1);
+	HIP_TRY(h, hipMemcpyAsync(h_poff.data(), d_poff, (size_t)(npairs + 1) * 8, hipMemcpyDeviceToHost, s));
 	HIP_TRY(h, hipStreamSynchronize(s));
 	for (int64_t p = 0; p < npairs; ++p)
-		if (out_score[p] == INT32_MIN || (tb && out_nops[p] < 0))
+		if (out_score[p] == INT32_MIN || out_nops[p] < 0)
 			return fail(h, AT_ERR_DOMAIN, "pair %lld: input outside the domain on which the reference is defined", (long long)(first_pair + p));
-	if (tb) {
-		const int64_t total = h_poff[(size_t)npairs];
-		if (total < 0 || total > slots_total) return fail(h, AT_ERR_DOMAIN, "traceback lengths inconsistent with the slots");
-		std::vector<uint8_t> pk((size_t)total + 1);
-		if (total) HIP_TRY(h, hipMemcpyAsync(pk.data(), h->d_str, (size_t)total, hipMemcpyDeviceToHost, s));
-		HIP_TRY(h, hipStreamSynchronize(s));
-		for (int64_t p = 0; p < npairs; ++p)
-			if (out_nops[p] > 0) memcpy(out_ops + ops_off[p], pk.data() + h_poff[(size_t)p], (size_t)out_nops[p]);
+	const int64_t total = h_poff[(size_t)npairs];
+	if (total < 0 || total > slots_total) return fail(h, AT_ERR_DOMAIN, "traceback lengths inconsistent with the slots");
+	std::vector<uint8_t> pk((size_t)total + 1);
+	if (total) HIP_TRY(h, hipMemcpyAsync(pk.data(), h->d_str, (size_t)total, hipMemcpyDeviceToHost, s));
+	HIP_TRY(h, hipStreamSynchronize(s));
+	for (int64_t p = 0; p < npairs; ++p)
+		if (out_nops[p] > 0) memcpy(out_ops + ops_off[p], pk.data() + h_poff[(size_t)p], (size_t)out_nops[p]);
+	return AT_OK;
+}
+
+extern "C" int at_align_allpairs(at_handle *h, int mode, int64_t nreads, const uint8_t *seq_blob,
+                                 const int64_t *off, const int32_t *len, int64_t first_pair, int64_t npairs, int want_traceback,
+                                 int32_t *out_score, int32_t *out_end_i, int32_t *out_end_j, int32_t *out_state,
+                                 uint8_t *out_ops, const int64_t *ops_off, int32_t *out_nops)
+{
+	int rc = check_allpairs_args(h, "at_align_allpairs", mode, nreads, first_pair, npairs);
+	if (rc) return rc;
+	if (npairs == 0) return AT_OK;
+	if (!seq_blob || !off || !len || !out_score) return fail(h, AT_ERR_ARG, "NULL argument");
+	const bool tb = want_traceback && mode != AT_MODE_EDIT;
+	if (tb && (!out_ops || !ops_off || !out_nops)) return fail(h, AT_ERR_ARG, "traceback wanted but ops buffers are NULL");
+	ReadSet rs;
+	rc = upload_reads(h, mode, nreads, seq_blob, off, len, &rs);
+	if (rc) return rc;
+	if (!tb) {
+		CopyOut co = {first_pair, out_score, out_end_i, out_end_j, out_state};
+		return allpairs_scores(h, mode, nreads, rs, first_pair, npairs, 0, copy_out_slice, &co);
+	}
+	/* with tracebacks: slices whose ops slots (2 * maxlen bytes per pair) stay below ~1 GiB of device memory */
+	const int64_t per = std::max<int64_t>(1, std::min<int64_t>(1LL << 22, (1LL << 30) / std::max(1, 2 * rs.maxlen)));
+	for (int64_t lo = 0; lo < npairs; lo += per) {
+		const int64_t n = std::min(per, npairs - lo);
+		rc = allpairs_tb_slice(h, mode, nreads, rs, first_pair + lo, n, out_score + lo, out_end_i ? out_end_i + lo : nullptr,
+		                       out_end_j ? out_end_j + lo : nullptr, out_state ? out_state + lo : nullptr, out_ops, ops_off + lo, out_nops + lo);
+		if (rc) return rc;
 	}
 	return AT_OK;
 }

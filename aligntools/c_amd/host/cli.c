@@ -10,6 +10,9 @@
  */
 #define _POSIX_C_SOURCE 200809L
 #include "at_host.h"
+#include <dirent.h>
+#include <math.h>
+#include <pthread.h>
 #include <signal.h>
 #include <stdint.h>
 #include <stdio.h>
@@ -116,7 +119,7 @@ static int main_single(int cmd, int argc, char *argv[])
 	return 0;
 }
 
-/* ---- batch extension: N pairs per file, one GPU batch per process ----
+/* ---- batch extension: N pairs per file ----
  *   alignTools batch <command> [options] [--score-only] [--all-vs-all] [--gpus N] <pairs.fa>
  *     default        records (2k, 2k+1) form pair k
  *     --all-vs-all   the records are reads; every ordered pair a < b is aligned as s1 = read a, s2 = read b (not for fit)
@@ -124,137 +127,393 @@ static int main_single(int cmd, int argc, char *argv[])
  *     --gpus N       one process per GPU: this process starts N workers (itself, with AT_RANK / AT_WORLD / AT_DEVICE /
  *                    AT_COMM_DIR in their environment), rank 0's options are broadcast over RCCL, every rank aligns a
  *                    contiguous share of the pairs on its own GPU, results are gathered over RCCL and rank 0 prints them
- *                    in pair order.  The output is that of --gpus 1. */
+ *                    in pair order.  The output is that of --gpus 1.
+ * One process streams: the file is parsed block-wise in chunks of pairs (fasta.c) on the main thread while a second
+ * thread -- which also pays the HIP start-up, in the shadow of the first chunks' parsing -- sends each chunk to the GPU
+ * and writes its results with one fwrite.  Memory is bounded by the chunks in flight, whatever the size of the file;
+ * --all-vs-all keeps the read set and streams slices of the triangle instead (at_align_allpairs_stream). */
 typedef struct { int score_only, all_vs_all, gpus; } batch_flags;
 
-/* linear index p of the strict upper triangle of n x n (row-major) -> (a, b), a < b */
-static void tri_pair(int64_t p, int64_t n, int64_t *a, int64_t *b)
+/* linear index p of the strict upper triangle of n x n (row-major) -> (a, b), a < b: closed form + integer correction */
+static void tri_seek(int64_t p, int64_t n, int64_t *a, int64_t *b)
 {
-	int64_t r = 0, before = 0;
-	while (before + (n - 1 - r) <= p) { before += n - 1 - r; ++r; }
-	*a = r; *b = r + 1 + (p - before);
+	const double d = (double)(2 * n - 1);
+	int64_t r = (int64_t)((d - sqrt(d * d - 8.0 * (double)p)) * 0.5);
+	if (r < 0) r = 0;
+	if (r > n - 2) r = n - 2;
+	while (r > 0 && r * (2 * n - r - 1) / 2 > p) --r;
+	while ((r + 1) * (2 * n - r - 2) / 2 <= p) ++r;
+	*a = r; *b = p - r * (2 * n - r - 1) / 2 + r + 1;
+}
+#define TRI_NEXT(a, b, n) do { if (++(b) >= (n)) { ++(a); (b) = (a) + 1; } } while (0)
+
+/* ---- output text of a chunk, written with one fwrite ---- */
+typedef struct { char *s; size_t l, m; } tbuf;
+static void tb_need(tbuf *t, size_t extra)
+{
+	if (t->l + extra <= t->m) return;
+	while (t->m < t->l + extra) t->m = t->m ? t->m * 2 : (size_t)1 << 20;
+	t->s = (char *)at_xrealloc(t->s, t->m);
+}
+static void tb_put(tbuf *t, const char *s, size_t n) { tb_need(t, n); memcpy(t->s + t->l, s, n); t->l += n; }
+/* "score=%f" of an integer-valued double / "edit_distance=%d", without printf */
+static void tb_score(tbuf *t, int32_t v, int is_edit)
+{
+	char d[16];
+	int n = 0;
+	uint32_t u = v < 0 ? 0u - (uint32_t)v : (uint32_t)v;
+	tb_need(t, 48);
+	if (is_edit) { memcpy(t->s + t->l, "edit_distance=", 14); t->l += 14; }
+	else { memcpy(t->s + t->l, "score=", 6); t->l += 6; }
+	if (v < 0) t->s[t->l++] = '-';
+	do { d[n++] = (char)('0' + u % 10); u /= 10; } while (u);
+	while (n) t->s[t->l++] = d[--n];
+	if (!is_edit) { memcpy(t->s + t->l, ".000000", 7); t->l += 7; }
+}
+/* "<name1>\t<name2>\t<score>\n[<r1>\n<r2>\n]" */
+static void tb_pair(tbuf *t, const char *na, const char *nb, int32_t score, int is_edit, const char *r1, const char *r2, size_t rl)
+{
+	const size_t la = strlen(na), lb = strlen(nb);
+	tb_need(t, la + lb + 2 * rl + 64);
+	memcpy(t->s + t->l, na, la); t->l += la; t->s[t->l++] = '\t';
+	memcpy(t->s + t->l, nb, lb); t->l += lb; t->s[t->l++] = '\t';
+	tb_score(t, score, is_edit);
+	t->s[t->l++] = '\n';
+	if (r1) {
+		memcpy(t->s + t->l, r1, rl); t->l += rl; t->s[t->l++] = '\n';
+		memcpy(t->s + t->l, r2, rl); t->l += rl; t->s[t->l++] = '\n';
+	}
+}
+static void tb_flush(tbuf *t)
+{
+	if (t->l && fwrite(t->s, 1, t->l, stdout) != t->l) die("write error on stdout");
+	t->l = 0;
+}
+
+/* ---- a slice of pairs: descriptors in, results out; buffers are reused from slice to slice ---- */
+typedef struct {
+	int64_t cap;
+	int64_t *off1, *off2, *slot;
+	int32_t *l1, *l2, *score, *ei, *ej, *st, *nops;
+	char *r1, *r2;
+	size_t rcap;
+} slice_t;
+
+static void slice_reserve(slice_t *w, int64_t n)
+{
+	if (n <= w->cap) return;
+	w->cap = n + n / 4 + 16;
+	w->off1 = (int64_t *)at_xrealloc(w->off1, (size_t)w->cap * 8); w->off2 = (int64_t *)at_xrealloc(w->off2, (size_t)w->cap * 8);
+	w->slot = (int64_t *)at_xrealloc(w->slot, (size_t)w->cap * 8);
+	w->l1 = (int32_t *)at_xrealloc(w->l1, (size_t)w->cap * 4); w->l2 = (int32_t *)at_xrealloc(w->l2, (size_t)w->cap * 4);
+	w->score = (int32_t *)at_xrealloc(w->score, (size_t)w->cap * 4); w->ei = (int32_t *)at_xrealloc(w->ei, (size_t)w->cap * 4);
+	w->ej = (int32_t *)at_xrealloc(w->ej, (size_t)w->cap * 4); w->st = (int32_t *)at_xrealloc(w->st, (size_t)w->cap * 4);
+	w->nops = (int32_t *)at_xrealloc(w->nops, (size_t)w->cap * 4);
+}
+static void slice_free(slice_t *w)
+{
+	free(w->off1); free(w->off2); free(w->slot); free(w->l1); free(w->l2); free(w->score); free(w->ei); free(w->ej); free(w->st);
+	free(w->nops); free(w->r1); free(w->r2);
+	memset(w, 0, sizeof *w);
+}
+/* off1 / l1 / off2 / l2 of pairs 0 .. n-1 are filled in: align them (strings rendered on the GPU when tb) */
+static void slice_run(slice_t *w, at_handle *h, int cmd, int tb, const uint8_t *blob, int64_t n)
+{
+	const int mode = cmd == C_GLOBAL ? AT_MODE_GLOBAL : cmd == C_LOCAL ? AT_MODE_LOCAL : cmd == C_FIT ? AT_MODE_FIT
+	               : cmd == C_OVERLAP ? AT_MODE_OVERLAP : AT_MODE_EDIT;
+	int64_t k, sl = 0;
+	int rc;
+	for (k = 0; k < n; ++k) {
+		if (cmd == C_FIT && w->l1[k] > w->l2[k]) die("first sequence must be shorter than the second\n");
+		w->slot[k] = sl; sl += (int64_t)w->l1[k] + w->l2[k] + 1;
+	}
+	if (n <= 0) return;
+	if (tb) {
+		if ((size_t)sl + 64 > w->rcap) {
+			w->rcap = (size_t)sl + (size_t)sl / 4 + 64;
+			free(w->r1); free(w->r2);
+			w->r1 = (char *)at_xmalloc(w->rcap); w->r2 = (char *)at_xmalloc(w->rcap);
+		}
+		rc = at_align_batch_strings(h, mode, n, blob, w->off1, w->l1, w->off2, w->l2, w->score, w->ei, w->ej, w->st, w->r1, w->r2, w->slot, w->nops);
+	} else
+		rc = at_align_batch(h, mode, n, blob, w->off1, w->l1, w->off2, w->l2, 0, w->score, w->ei, w->ej, w->st, NULL, NULL, NULL);
+	if (rc != AT_OK) die("%s", at_last_error(h));
+}
+
+static int64_t env_i64(const char *name, int64_t dflt)
+{
+	const char *v = getenv(name);
+	return v && *v ? (int64_t)atoll(v) : dflt;
+}
+
+static void set_sites(opt_t *opt, const at_chunk *c)
+{
+	if (opt->s != AT_TRUE) return;
+	if (c->n < 2 || c->comment_off[1] == (size_t)-1) die("fail to read junction sites");
+	opt->sites.size = (size_t)at_parse_sites(c->comments + c->comment_off[1], &opt->sites.pos);
+}
+
+static void *gpu_warmup(void *unused) { (void)unused; (void)at_host_handle(); return NULL; }
+
+/* ---- pair lists in one process: reader (main thread) -> ring of chunks -> GPU + output (second thread) ---- */
+#define RING 4
+typedef struct {
+	pthread_mutex_t mu;
+	pthread_cond_t cv;
+	at_chunk chunk[RING];
+	int filled[RING];            /* 1: parsed, waiting for the GPU thread */
+	int head, tail, closed;      /* the reader fills `tail`, the GPU thread takes `head` */
+	int cmd, tb;
+	opt_t *opt;
+} pipe_t;
+
+static void *pipe_consumer(void *arg)
+{
+	pipe_t *pp = (pipe_t *)arg;
+	at_handle *h = at_host_handle();                /* HIP start-up: in the shadow of the reader */
+	slice_t w;
+	tbuf out = {NULL, 0, 0};
+	const opt_t *opt = pp->opt;
+	int rc = at_set_scoring(h, opt->m, opt->u, opt->o, opt->e, opt->j, opt->s == AT_TRUE, opt->sites.pos, (int)opt->sites.size);
+	if (rc != AT_OK) die("%s", at_last_error(h));
+	memset(&w, 0, sizeof w);
+	for (;;) {
+		at_chunk *c;
+		int64_t n, k;
+		pthread_mutex_lock(&pp->mu);
+		while (!pp->filled[pp->head] && !pp->closed) pthread_cond_wait(&pp->cv, &pp->mu);
+		if (!pp->filled[pp->head]) { pthread_mutex_unlock(&pp->mu); break; }
+		c = &pp->chunk[pp->head];
+		pthread_mutex_unlock(&pp->mu);
+		n = (int64_t)(c->n / 2);
+		slice_reserve(&w, n);
+		for (k = 0; k < n; ++k) {
+			w.off1[k] = (int64_t)c->off[2 * k]; w.l1[k] = (int32_t)c->len[2 * k];
+			w.off2[k] = (int64_t)c->off[2 * k + 1]; w.l2[k] = (int32_t)c->len[2 * k + 1];
+		}
+		slice_run(&w, h, pp->cmd, pp->tb, c->blob, n);
+		for (k = 0; k < n; ++k)
+			tb_pair(&out, c->names + c->name_off[2 * k], c->names + c->name_off[2 * k + 1], w.score[k], pp->cmd == C_EDIT,
+			        pp->tb ? w.r1 + w.slot[k] : NULL, pp->tb ? w.r2 + w.slot[k] : NULL, pp->tb ? (size_t)w.nops[k] : 0);
+		tb_flush(&out);
+		pthread_mutex_lock(&pp->mu);
+		pp->filled[pp->head] = 0;
+		pp->head = (pp->head + 1) % RING;
+		pthread_cond_broadcast(&pp->cv);
+		pthread_mutex_unlock(&pp->mu);
+	}
+	slice_free(&w);
+	free(out.s);
+	return NULL;
+}
+
+static int batch_stream_pairs(int cmd, opt_t *opt, int tb, at_reader *rd)
+{
+	pipe_t *pp = (pipe_t *)at_xmalloc(sizeof *pp);
+	pthread_t th;
+	int started = 0, q;
+	size_t total = 0;
+	const size_t first_pairs = (size_t)env_i64("AT_CLI_FIRST_CHUNK", 8192), chunk_pairs = (size_t)env_i64("AT_CLI_CHUNK", 32768);
+	const size_t max_bases = (size_t)env_i64("AT_CLI_CHUNK_BASES", (int64_t)256 << 20);
+	memset(pp, 0, sizeof *pp);
+	pthread_mutex_init(&pp->mu, NULL);
+	pthread_cond_init(&pp->cv, NULL);
+	pp->cmd = cmd; pp->tb = tb; pp->opt = opt;
+	for (;;) {
+		at_chunk *c;
+		size_t got;
+		pthread_mutex_lock(&pp->mu);
+		while (pp->filled[pp->tail]) pthread_cond_wait(&pp->cv, &pp->mu);   /* every slot is waiting for the GPU: the reader pauses */
+		c = &pp->chunk[pp->tail];
+		pthread_mutex_unlock(&pp->mu);
+		at_chunk_reset(c);
+		got = at_reader_read(rd, 2 * (started ? chunk_pairs : first_pairs), max_bases, c);
+		if (got & 1) got += at_reader_read(rd, 1, (size_t)-1, c);          /* (the bases limit fell between the two records of a pair) */
+		total += got;
+		if (!started) {
+			/* the first chunk decides what a small file's errors are, before any thread or GPU exists */
+			if (total < 2 || (got & 1)) die("batch input needs an even number of records (got %d)", (int)total);
+			set_sites(opt, c);
+		}
+		if (got == 0) break;
+		if (got & 1) {          /* an odd record at the very end of a file of several chunks */
+			pthread_mutex_lock(&pp->mu); pp->closed = 1; pthread_cond_broadcast(&pp->cv); pthread_mutex_unlock(&pp->mu);
+			pthread_join(th, NULL);
+			die("batch input needs an even number of records (got %d)", (int)total);
+		}
+		pthread_mutex_lock(&pp->mu);
+		pp->filled[pp->tail] = 1;
+		pp->tail = (pp->tail + 1) % RING;
+		pthread_cond_broadcast(&pp->cv);
+		pthread_mutex_unlock(&pp->mu);
+		if (!started) {
+			if (pthread_create(&th, NULL, pipe_consumer, pp) != 0) die("cannot start the GPU thread");
+			started = 1;
+		}
+	}
+	pthread_mutex_lock(&pp->mu); pp->closed = 1; pthread_cond_broadcast(&pp->cv); pthread_mutex_unlock(&pp->mu);
+	if (started) pthread_join(th, NULL);
+	for (q = 0; q < RING; ++q) at_chunk_free(&pp->chunk[q]);
+	pthread_mutex_destroy(&pp->mu); pthread_cond_destroy(&pp->cv);
+	free(pp);
+	return 0;
+}
+
+/* ---- everything else keeps the whole record set: --all-vs-all, and the ranks of --gpus N ---- */
+typedef struct { const at_chunk *c; int64_t a, b, nrec; int is_edit; tbuf out; } ava_print;
+
+static int print_slice(void *user, int64_t first, int64_t n, const int32_t *score, const int32_t *ei, const int32_t *ej, const int32_t *st)
+{
+	ava_print *ap = (ava_print *)user;
+	int64_t k;
+	(void)first; (void)ei; (void)ej; (void)st;
+	for (k = 0; k < n; ++k) {
+		tb_pair(&ap->out, ap->c->names + ap->c->name_off[ap->a], ap->c->names + ap->c->name_off[ap->b], score[k], ap->is_edit, NULL, NULL, 0);
+		TRI_NEXT(ap->a, ap->b, ap->nrec);
+		if (ap->out.l > ((size_t)8 << 20)) tb_flush(&ap->out);
+	}
+	tb_flush(&ap->out);
+	return 0;
 }
 
 static int batch_worker(int cmd, opt_t *opt, const batch_flags *bf, const char *fname, int rank, int world, const char *comm_dir)
 {
-	at_records rec;
+	at_reader *rd = at_reader_open(fname);
+	at_chunk c;
 	at_handle *h;
-	int mode, rc;
-	size_t nrec, p, tot = 0;
-	int64_t npairs, lo, hi, n, k;
-	uint8_t *blob;
-	int64_t *roff, *off1, *off2, *slot;
-	int32_t *rlen, *l1, *l2, *score, *ei, *ej, *st, *nops;
-	char *r1 = NULL, *r2 = NULL;
+	pthread_t warm;
+	slice_t w;
+	tbuf out = {NULL, 0, 0};
+	int rc;
+	int64_t nrec, npairs, lo, hi, a = 0, b = 0;
+	int64_t *roff = NULL;
+	int32_t *rlen = NULL;
 	const int tb = !bf->score_only && cmd != C_EDIT;
-	if (at_read_records(fname, &rec) != 0) die("Can't open %s\n", fname);
-	nrec = rec.n;
-	if (bf->all_vs_all) {
-		if (cmd == C_FIT) die("--all-vs-all: fit needs ordered pairs (first sequence shorter than the second)");
-		if (nrec < 2) die("--all-vs-all needs at least two records (got %d)", (int)nrec);
-		npairs = (int64_t)nrec * ((int64_t)nrec - 1) / 2;
-	} else {
-		if (nrec < 2 || (nrec & 1)) die("batch input needs an even number of records (got %d)", (int)nrec);
-		npairs = (int64_t)nrec / 2;
+	const int comm = world > 1 || getenv("AT_COMM_FORCE_RCCL") != NULL;   /* (the latter: the RCCL calls at world size 1, for tests) */
+	const int mode = cmd == C_GLOBAL ? AT_MODE_GLOBAL : cmd == C_LOCAL ? AT_MODE_LOCAL : cmd == C_FIT ? AT_MODE_FIT
+	               : cmd == C_OVERLAP ? AT_MODE_OVERLAP : AT_MODE_EDIT;
+	const int64_t chunk_pairs = env_i64("AT_CLI_CHUNK", 32768) * 8;
+	if (!rd) die("Can't open %s\n", fname);
+	if (bf->all_vs_all && cmd == C_FIT) die("--all-vs-all: fit needs ordered pairs (first sequence shorter than the second)");
+	if (!bf->all_vs_all && !comm) {
+		rc = batch_stream_pairs(cmd, opt, tb, rd);
+		at_reader_close(rd);
+		return rc;
 	}
-	if (opt->s == AT_TRUE) {
-		if (rec.comment[1] == NULL) die("fail to read junction sites");
-		opt->sites.size = (size_t)at_parse_sites(rec.comment[1], &opt->sites.pos);
-	}
-	for (p = 0; p < nrec; ++p) tot += rec.len[p];
-	blob = (uint8_t *)at_xmalloc(tot + 1);
-	roff = (int64_t *)at_xmalloc(nrec * 8); rlen = (int32_t *)at_xmalloc(nrec * 4);
-	tot = 0;
-	for (p = 0; p < nrec; ++p) {
-		roff[p] = (int64_t)tot; rlen[p] = (int32_t)rec.len[p];
-		memcpy(blob + tot, rec.seq[p], rec.len[p]); tot += rec.len[p];
-	}
+	memset(&c, 0, sizeof c);
+	memset(&w, 0, sizeof w);
+	/* the first records decide whether there is anything to do; then HIP starts up beside the rest of the parsing */
+	(void)at_reader_read(rd, 4, (size_t)-1, &c);
+	if (bf->all_vs_all && c.n < 2) die("--all-vs-all needs at least two records (got %d)", (int)c.n);
+	if (!bf->all_vs_all && c.n < 2) die("batch input needs an even number of records (got %d)", (int)c.n);
+	set_sites(opt, &c);
+	if (pthread_create(&warm, NULL, gpu_warmup, NULL) != 0) die("cannot start the GPU thread");
+	while (at_reader_read(rd, (size_t)-1, (size_t)-1, &c) > 0) {}
+	at_reader_close(rd);
+	pthread_join(warm, NULL);
+	nrec = (int64_t)c.n;
+	if (!bf->all_vs_all && (nrec & 1)) die("batch input needs an even number of records (got %d)", (int)nrec);
+	npairs = bf->all_vs_all ? nrec * (nrec - 1) / 2 : nrec / 2;
 	/* this rank's contiguous share of the pairs: rank r owns [ceil(n r / N), ceil(n (r + 1) / N)) */
 	lo = (npairs * rank + world - 1) / world;
 	hi = (npairs * (rank + 1) + world - 1) / world;
 	if (hi > npairs) hi = npairs;
-	n = hi - lo;
-	off1 = (int64_t *)at_xmalloc((size_t)(n + 1) * 8); off2 = (int64_t *)at_xmalloc((size_t)(n + 1) * 8); slot = (int64_t *)at_xmalloc((size_t)(n + 1) * 8);
-	l1 = (int32_t *)at_xmalloc((size_t)(n + 1) * 4); l2 = (int32_t *)at_xmalloc((size_t)(n + 1) * 4);
-	score = (int32_t *)at_xmalloc((size_t)(n + 1) * 4); ei = (int32_t *)at_xmalloc((size_t)(n + 1) * 4); ej = (int32_t *)at_xmalloc((size_t)(n + 1) * 4);
-	st = (int32_t *)at_xmalloc((size_t)(n + 1) * 4); nops = (int32_t *)at_xmalloc((size_t)(n + 1) * 4);
-	{
-		int64_t sl = 0, a = 0, b = 0;
-		for (k = 0; k < n; ++k) {
-			if (bf->all_vs_all) tri_pair(lo + k, (int64_t)nrec, &a, &b); else { a = 2 * (lo + k); b = a + 1; }
-			off1[k] = roff[a]; l1[k] = rlen[a]; off2[k] = roff[b]; l2[k] = rlen[b];
-			slot[k] = sl; sl += (int64_t)l1[k] + l2[k] + 1;
-			if (cmd == C_FIT && l1[k] > l2[k]) die("first sequence must be shorter than the second\n");
-		}
-		if (tb) { r1 = (char *)at_xmalloc((size_t)sl + 64); r2 = (char *)at_xmalloc((size_t)sl + 64); }
-	}
-	mode = cmd == C_GLOBAL ? AT_MODE_GLOBAL : cmd == C_LOCAL ? AT_MODE_LOCAL : cmd == C_FIT ? AT_MODE_FIT
-	     : cmd == C_OVERLAP ? AT_MODE_OVERLAP : AT_MODE_EDIT;
 	h = at_host_handle();
 	rc = at_set_scoring(h, opt->m, opt->u, opt->o, opt->e, opt->j, opt->s == AT_TRUE, opt->sites.pos, (int)opt->sites.size);
-	const int comm = world > 1 || getenv("AT_COMM_FORCE_RCCL") != NULL;   /* (the latter: the RCCL calls at world size 1, for tests) */
 	if (rc == AT_OK && comm) {
 		rc = at_comm_init(h, rank, world, comm_dir);
 		if (rc == AT_OK) rc = at_comm_broadcast_scoring(h);      /* rank 0's options are everybody's */
 	}
-	if (rc == AT_OK && n > 0) {
-		if (bf->all_vs_all && !tb)   /* scores of a slice of the triangle: the reads go up once, the pairs are enumerated on the GPU */
-			rc = at_align_allpairs(h, mode, (int64_t)nrec, blob, roff, rlen, lo, n, 0, score, ei, ej, st, NULL, NULL, NULL);
-		else if (!tb)
-			rc = at_align_batch(h, mode, n, blob, off1, l1, off2, l2, 0, score, ei, ej, st, NULL, NULL, NULL);
-		else        /* strings are rendered on the GPU (at_render.hip.h) */
-			rc = at_align_batch_strings(h, mode, n, blob, off1, l1, off2, l2, score, ei, ej, st, r1, r2, slot, nops);
-	}
 	if (rc != AT_OK) die("%s", at_last_error(h));
-	if (!comm) {
-		int64_t a = 0, b = 0;
-		for (k = 0; k < n; ++k) {
-			if (bf->all_vs_all) tri_pair(lo + k, (int64_t)nrec, &a, &b); else { a = 2 * (lo + k); b = a + 1; }
-			if (cmd == C_EDIT) printf("%s\t%s\tedit_distance=%d\n", rec.name[a], rec.name[b], score[k]);
-			else if (!tb) printf("%s\t%s\tscore=%f\n", rec.name[a], rec.name[b], (double)score[k]);
-			else printf("%s\t%s\tscore=%f\n%s\n%s\n", rec.name[a], rec.name[b], (double)score[k], r1 + slot[k], r2 + slot[k]);
-		}
-	} else {
-		/* gather: the scores (4 bytes per pair) and, with tracebacks, every pair's two strings back to back with their
-		 * terminators -- at_comm_allgather sends the sizes first, then one padded payload; rank 0 prints */
-		int64_t *bytes = (int64_t *)at_xmalloc((size_t)world * 8), paylen = 0, o, q;
-		int32_t *allscore = (int32_t *)at_xmalloc((size_t)(npairs + 1) * 4);
-		char *pay = NULL, *allpay = NULL;
-		rc = at_comm_allgather(h, score, n * 4, allscore, npairs * 4, bytes);
-		if (rc == AT_OK && tb) {
-			int64_t cap = 0;
-			for (p = 0; p < nrec; ++p) cap += (int64_t)rec.len[p];
-			for (k = 0; k < n; ++k) paylen += 2 * ((int64_t)nops[k] + 1);
-			pay = (char *)at_xmalloc((size_t)paylen + 1);
-			for (k = 0, o = 0; k < n; ++k) {
-				memcpy(pay + o, r1 + slot[k], (size_t)nops[k] + 1); o += nops[k] + 1;
-				memcpy(pay + o, r2 + slot[k], (size_t)nops[k] + 1); o += nops[k] + 1;
-			}
-			/* an upper bound of everything: every pair's strings are at most l1 + l2 + 1 long, twice */
-			cap = bf->all_vs_all ? 2 * ((int64_t)(nrec - 1) * cap + npairs) : 2 * (cap + npairs);
-			allpay = (char *)at_xmalloc((size_t)cap + 1);
-			rc = at_comm_allgather(h, pay, paylen, allpay, cap, bytes);
-		}
-		if (rc != AT_OK) die("%s", at_last_error(h));
-		if (rank == 0) {
-			int64_t a = 0, b = 0;
-			for (q = 0, o = 0; q < npairs; ++q) {
-				if (bf->all_vs_all) tri_pair(q, (int64_t)nrec, &a, &b); else { a = 2 * q; b = a + 1; }
-				if (cmd == C_EDIT) printf("%s\t%s\tedit_distance=%d\n", rec.name[a], rec.name[b], allscore[q]);
-				else if (!tb) printf("%s\t%s\tscore=%f\n", rec.name[a], rec.name[b], (double)allscore[q]);
-				else {
-					const char *x = allpay + o, *y = x + strlen(x) + 1;
-					printf("%s\t%s\tscore=%f\n%s\n%s\n", rec.name[a], rec.name[b], (double)allscore[q], x, y);
-					o += 2 * ((int64_t)strlen(x) + 1);
-				}
-			}
-		}
-		at_comm_destroy(h);
-		free(bytes); free(allscore); free(pay); free(allpay);
+	if (bf->all_vs_all) {
+		int64_t k;
+		roff = (int64_t *)at_xmalloc((size_t)nrec * 8); rlen = (int32_t *)at_xmalloc((size_t)nrec * 4);
+		for (k = 0; k < nrec; ++k) { roff[k] = (int64_t)c.off[k]; rlen[k] = (int32_t)c.len[k]; }
 	}
-	free(blob); free(roff); free(rlen); free(off1); free(off2); free(slot);
-	free(l1); free(l2); free(score); free(ei); free(ej); free(st); free(nops); free(r1); free(r2);
-	at_free_records(&rec);
+	if (!comm && !tb) {
+		/* scores of the whole triangle: the reads go up once, the pairs are enumerated on the GPU, slices are printed as they arrive */
+		ava_print ap;
+		memset(&ap, 0, sizeof ap);
+		ap.c = &c; ap.nrec = nrec; ap.is_edit = cmd == C_EDIT; ap.a = 0; ap.b = 1;
+		rc = at_align_allpairs_stream(h, mode, nrec, c.blob, roff, rlen, 0, npairs, env_i64("AT_CLI_CHUNK", 0), print_slice, &ap);
+		if (rc != AT_OK) die("%s", at_last_error(h));
+		free(ap.out.s);
+	} else {
+		/* slices of this rank's share; one process prints every slice, a rank of many collects its share for the gather */
+		int32_t *myscore = comm ? (int32_t *)at_xmalloc((size_t)(hi - lo + 1) * 4) : NULL;
+		tbuf pay = {NULL, 0, 0};
+		int64_t s0, k;
+		if (bf->all_vs_all && hi > lo) tri_seek(lo, nrec, &a, &b);
+		for (s0 = lo; s0 < hi; s0 += chunk_pairs) {
+			const int64_t n = hi - s0 < chunk_pairs ? hi - s0 : chunk_pairs;
+			int64_t a0 = a, b0 = b;
+			slice_reserve(&w, n);
+			if (bf->all_vs_all && !tb) {
+				rc = at_align_allpairs(h, mode, nrec, c.blob, roff, rlen, s0, n, 0, w.score, w.ei, w.ej, w.st, NULL, NULL, NULL);
+				if (rc != AT_OK) die("%s", at_last_error(h));
+				for (k = 0; k < n; ++k) TRI_NEXT(a, b, nrec);
+			} else {
+				for (k = 0; k < n; ++k) {
+					const int64_t ra = bf->all_vs_all ? a : 2 * (s0 + k), rb = bf->all_vs_all ? b : 2 * (s0 + k) + 1;
+					w.off1[k] = (int64_t)c.off[ra]; w.l1[k] = (int32_t)c.len[ra]; w.off2[k] = (int64_t)c.off[rb]; w.l2[k] = (int32_t)c.len[rb];
+					if (bf->all_vs_all) TRI_NEXT(a, b, nrec);
+				}
+				slice_run(&w, h, cmd, tb, c.blob, n);
+			}
+			if (!comm) {
+				for (k = 0; k < n; ++k) {
+					const int64_t ra = bf->all_vs_all ? a0 : 2 * (s0 + k), rb = bf->all_vs_all ? b0 : 2 * (s0 + k) + 1;
+					tb_pair(&out, c.names + c.name_off[ra], c.names + c.name_off[rb], w.score[k], cmd == C_EDIT,
+					        tb ? w.r1 + w.slot[k] : NULL, tb ? w.r2 + w.slot[k] : NULL, tb ? (size_t)w.nops[k] : 0);
+					if (bf->all_vs_all) TRI_NEXT(a0, b0, nrec);
+				}
+				tb_flush(&out);
+			} else {
+				memcpy(myscore + (s0 - lo), w.score, (size_t)n * 4);
+				if (tb)
+					for (k = 0; k < n; ++k) {   /* every pair's two strings back to back with their terminators */
+						tb_put(&pay, w.r1 + w.slot[k], (size_t)w.nops[k] + 1);
+						tb_put(&pay, w.r2 + w.slot[k], (size_t)w.nops[k] + 1);
+					}
+			}
+		}
+		if (comm) {
+			/* gather: the scores (4 bytes per pair) and, with tracebacks, the strings -- at_comm_allgather sends the sizes
+			 * first, then one padded payload; rank 0 prints everything in pair order */
+			int64_t *bytes = (int64_t *)at_xmalloc((size_t)world * 8), o = 0, q;
+			int32_t *allscore = (int32_t *)at_xmalloc((size_t)(npairs + 1) * 4);
+			char *allpay = NULL;
+			rc = at_comm_allgather(h, myscore, (hi - lo) * 4, allscore, npairs * 4, bytes);
+			if (rc == AT_OK && tb) {
+				int64_t mine = (int64_t)pay.l, total = 0, *sizes = (int64_t *)at_xmalloc((size_t)world * 8);
+				rc = at_comm_allgather(h, &mine, 8, sizes, (int64_t)world * 8, bytes);          /* how much to expect in all */
+				for (q = 0; rc == AT_OK && q < world; ++q) total += sizes[q];
+				allpay = (char *)at_xmalloc((size_t)total + 1);
+				if (rc == AT_OK) rc = at_comm_allgather(h, pay.s, mine, allpay, total, bytes);
+				free(sizes);
+			}
+			if (rc != AT_OK) die("%s", at_last_error(h));
+			if (rank == 0) {
+				a = 0; b = 1;
+				for (q = 0; q < npairs; ++q) {
+					const int64_t ra = bf->all_vs_all ? a : 2 * q, rb = bf->all_vs_all ? b : 2 * q + 1;
+					const char *x = tb ? allpay + o : NULL;
+					const size_t xl = tb ? strlen(x) : 0;
+					tb_pair(&out, c.names + c.name_off[ra], c.names + c.name_off[rb], allscore[q], cmd == C_EDIT, x, tb ? x + xl + 1 : NULL, xl);
+					if (tb) o += 2 * ((int64_t)xl + 1);
+					if (bf->all_vs_all) TRI_NEXT(a, b, nrec);
+					if (out.l > ((size_t)8 << 20)) tb_flush(&out);
+				}
+				tb_flush(&out);
+			}
+			at_comm_destroy(h);
+			free(bytes); free(allscore); free(allpay);
+		}
+		free(myscore); free(pay.s);
+	}
+	slice_free(&w);
+	free(out.s); free(roff); free(rlen);
+	at_chunk_free(&c);
 	return 0;
 }
 
@@ -263,7 +522,7 @@ static int batch_launch(int world, char *argv0, int argc, char *argv[])
 {
 	char dir[] = "/tmp/alignTools.XXXXXX", buf[32];
 	pid_t *pid = (pid_t *)at_xmalloc((size_t)world * sizeof(pid_t));
-	int r, status, worst = 0;
+	int r, status, worst = 0, live = 0;
 	char **av = (char **)at_xmalloc((size_t)(argc + 2) * sizeof(char *));
 	if (!mkdtemp(dir)) die("cannot create a rendezvous directory under /tmp");
 	av[0] = argv0;
@@ -281,21 +540,33 @@ static int batch_launch(int world, char *argv0, int argc, char *argv[])
 			execv("/proc/self/exe", av);
 			_exit(127);
 		}
+		++live;
 	}
-	/* a rank that fails leaves the others waiting in a collective: the first failure ends them all */
-	for (r = 0; r < world; ++r) {
+	/* a rank that fails leaves the others waiting in a collective: the first failure ends the ranks that are still running
+	 * (pids of ranks already reaped are forgotten, so that a recycled pid is never signalled) */
+	while (live > 0) {
 		const pid_t done = waitpid(-1, &status, 0);
 		int q, code = done < 0 || !WIFEXITED(status) ? 255 : WEXITSTATUS(status);
+		if (done < 0) break;
+		for (q = 0; q < world; ++q) if (pid[q] == done) { pid[q] = 0; --live; }
 		if (code > worst) worst = code;
-		if (code != 0) {
-			for (q = 0; q < world; ++q) if (pid[q] != done) kill(pid[q], SIGTERM);
-		}
+		if (code != 0)
+			for (q = 0; q < world; ++q) if (pid[q] > 0) kill(pid[q], SIGTERM);
 	}
 	/* the rendezvous directory held a few small files */
 	{
-		char cmdline[96];
-		snprintf(cmdline, sizeof cmdline, "rm -rf %s", dir);
-		if (system(cmdline) != 0) worst = worst ? worst : 0;
+		DIR *d = opendir(dir);
+		if (d) {
+			struct dirent *e;
+			char path[512];
+			while ((e = readdir(d)) != NULL) {
+				if (strcmp(e->d_name, ".") == 0 || strcmp(e->d_name, "..") == 0) continue;
+				snprintf(path, sizeof path, "%s/%s", dir, e->d_name);
+				(void)unlink(path);
+			}
+			closedir(d);
+		}
+		(void)rmdir(dir);
 	}
 	free(pid); free(av);
 	return worst;

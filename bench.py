@@ -113,6 +113,35 @@ def cpu_baseline(mode, l1, l2, scoring, use_jump, sites, seed, target_s=15.0):
                 gcups_all_cores=multi, gcups_1core=single, host_cores_used=d["cores"])
 
 
+def launch_ranks(n, backend):
+    """Start `python -m torch.distributed.run --nnodes=1 --nproc-per-node n ... bench.py <same arguments>` as a child process (never
+    an exec), pass its stderr through, relay the one JSON line rank 0 prints, return its exit code."""
+    import socket
+    try:   # (counting devices initialises nothing on the GPU)
+        import torch
+        have = torch.cuda.device_count()
+    except Exception:
+        have = 0
+    if backend == "nccl" and have < n and not os.environ.get("BENCH_LAUNCH_DRYRUN"):
+        sys.stderr.write("bench.py: --gpus %d but this node shows %d GPU(s): RCCL takes one rank per device "
+                         "(--backend gloo rehearses the pipeline with ranks sharing a card)\n" % (n, have))
+        return 2
+    with socket.socket() as so:   # a free rendezvous port on the loopback
+        so.bind(("127.0.0.1", 0))
+        port = so.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    if os.environ.get("BENCH_LAUNCH_DRYRUN"):   # (tests without a GPU: what would be started)
+        sys.stderr.write("bench.py: would start: %s\n" % " ".join(cmd))
+        return 0
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    p = subprocess.Popen(cmd, cwd=ROOT, env=env, stdout=subprocess.PIPE, text=True)
+    for line in p.stdout:      # rank 0's JSON line goes to stdout; anything else a library printed there goes to stderr
+        (sys.stdout if line.lstrip().startswith("{") else sys.stderr).write(line)
+        sys.stdout.flush()
+    return p.wait()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -148,10 +177,13 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     use_dist = "RANK" in os.environ and "MASTER_ADDR" in os.environ   # launched by torch.distributed.run (any N)
+    if args.gpus > 1 and not use_dist:
+        # `python bench.py --gpus N` without a launcher: this process becomes the launcher.  It has made no GPU call and makes
+        # none; the ranks are its grandchildren (torch.distributed.run, one rank per GPU), their one JSON line is relayed.
+        sys.exit(launch_ranks(args.gpus, args.backend))
     if args.gpus != world:
-        sys.exit("bench.py: --gpus %d but WORLD_SIZE is %d -- launch N > 1 with `python -m torch.distributed.run --nnodes=1 "
-                 "--nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...` (one rank per GPU)"
-                 % (args.gpus, world))
+        sys.exit("bench.py: --gpus %d but WORLD_SIZE is %d (one rank per GPU: `python bench.py --gpus N` starts its own "
+                 "torch.distributed.run, or start it under one with --nproc-per-node N)" % (args.gpus, world))
     mode, l1, l2, pairs, scoring, use_jump, sites, seed = WORKLOADS[args.workload]
     if args.pairs:
         pairs = args.pairs
@@ -201,6 +233,14 @@ def main():
         sys.stdout.flush()
         os.dup2(saved_stdout, 1)
         os.close(saved_stdout)
+    ranks_info = None
+    if use_dist:
+        # who took part: every rank's device, as the process group sees it (config.gather.ranks of the JSON line)
+        pr = torch.cuda.get_device_properties(local_rank)
+        me = {"rank": rank, "pid": os.getpid(), "device": local_rank, "name": pr.name,
+              "pci_bus_id": "%04x:%02x:%02x" % (getattr(pr, "pci_domain_id", 0), getattr(pr, "pci_bus_id", 0), getattr(pr, "pci_device_id", 0))}
+        ranks_info = [None] * world
+        dist.all_gather_object(ranks_info, me)
     scl = sc.cpu().tolist()
     m, u, o, e, j, uj, ns = scl[:7]
     site_list = st.cpu().tolist()[:ns]
@@ -435,7 +475,12 @@ def main():
         gb, row, rows = grp_of[last] % NGB, row_of[last], row_of[last] + 1
         gnp = gathered[gb].cpu().numpy()
         assert (gnp[rank, :rows] == grp_res[gb][:rows].cpu().numpy()).all(), "fixed-size gather: own block differs"
-        gather_info = {"steps_per_collective": G, "fixed_bytes_per_rank_and_step": 20 * pairs}
+        try:
+            bver = ".".join(str(x) for x in torch.cuda.nccl.version()) if args.backend == "nccl" else None
+        except Exception:
+            bver = None
+        gather_info = {"world": world, "backend": "nccl (RCCL %s)" % bver if args.backend == "nccl" else "gloo (rehearsal: ranks may share a card)",
+                       "ranks": ranks_info, "steps_per_collective": G, "fixed_bytes_per_rank_and_step": 20 * pairs}
         if cig:
             # every rank's total per step is the sum of its gathered nops, and this rank's part of the payload is its own ops
             # slots back to back

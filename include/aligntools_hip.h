@@ -159,6 +159,20 @@ int at_align_allpairs(at_handle *h, int mode, int64_t nreads,
                       uint8_t *out_ops, const int64_t *ops_off, int32_t *out_nops);
 
 /*
+ * The same sweep with bounded memory, for triangles too large to hold (C5: 50 000 reads = 1.25e9 pairs = 20 GB of
+ * results): scores and end cells only, the triangle cut into slices of at most chunk_pairs pairs (<= 0: 4 Mi); `fn`
+ * is called once per slice, in pair order, on the calling thread, while the GPU already sweeps the next slice.  The
+ * arrays it sees (indexed by pair - first) are valid during the call only; a non-zero return stops the sweep
+ * (AT_ERR_ARG).  at_align_allpairs without tracebacks is this entry with a callback that copies into its out arrays.
+ */
+typedef int (*at_allpairs_chunk_fn)(void *user, int64_t first, int64_t npairs,
+                                    const int32_t *score, const int32_t *end_i, const int32_t *end_j, const int32_t *state);
+int at_align_allpairs_stream(at_handle *h, int mode, int64_t nreads,
+                             const uint8_t *seq_blob, const int64_t *off, const int32_t *len,
+                             int64_t first_pair, int64_t npairs, int64_t chunk_pairs,
+                             at_allpairs_chunk_fn fn, void *user);
+
+/*
  * Output rendering on the GPU: what trace_back_* + strrev produce (alignment.h:372-412,
  * 558-592, 766-800, 896-922, 172-184) -- the two gapped strings, in reading order -- from the op codes and end
  * cells at_align_batch_device left in HBM and the same packed sequences.  Pair k's strings are written to
@@ -206,6 +220,9 @@ int at_comm_init(at_handle *h, int rank, int world, const char *dir);
 int at_comm_broadcast_scoring(at_handle *h);
 int at_comm_allgather(at_handle *h, const void *mine, int64_t mine_bytes, void *all, int64_t all_cap, int64_t *bytes_of_rank);
 void at_comm_destroy(at_handle *h);
+/* 1 if the library's hand-written RCCL declarations were checked against the installed <rccl/rccl.h> when it was built
+ * (static_asserts in csrc/at_comm.hip: id size, enum values, every entry point's argument list), 0 if no header was there */
+int at_comm_abi_checked(void);
 
 /* Host helper: pack `npairs` pairs of raw bytes into the word layout above.
  * bits = 0 picks 2 when every byte is one of ACGT, else 8; the choice is

@@ -39,10 +39,39 @@ def test_bench_prints_one_json_line():
     assert d["value"] > 100 and abs(d["ms_per_step"] * d["value"] - 30000 * 150 * 150 / 1e6) < 1e-3 * d["ms_per_step"] * d["value"]
 
 
-def test_bench_refuses_gpus_without_launcher():
+def test_bench_gpus_n_starts_its_own_launcher():
+    """`python bench.py --gpus N` with no launcher in the environment (the way the driver runs N = 1) must not fail: it starts
+    `python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N` as a child.  Without a GPU: the dry run names it."""
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
-    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2"], capture_output=True, text=True, timeout=120, env=env)
-    assert p.returncode != 0 and "torch.distributed.run" in p.stderr and p.stdout.strip() == ""
+    env["BENCH_LAUNCH_DRYRUN"] = "1"
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "4", "--steps", "7", "--warmup", "2"],
+                       capture_output=True, text=True, timeout=300, env=env)
+    assert p.returncode == 0 and p.stdout.strip() == "", p.stderr[-2000:]
+    assert "-m torch.distributed.run --nnodes=1 --nproc-per-node 4 --master-addr 127.0.0.1 --master-port" in p.stderr
+    assert p.stderr.rstrip().endswith("bench.py --gpus 4 --steps 7 --warmup 2")
+
+
+def test_bench_refuses_more_ranks_than_gpus_over_rccl():
+    """RCCL takes one rank per device: asking for more ranks than the node has GPUs is refused before anything starts."""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT", "BENCH_LAUNCH_DRYRUN")}
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "64"], capture_output=True, text=True, timeout=300, env=env)
+    assert p.returncode == 2 and "one rank per device" in p.stderr and p.stdout.strip() == ""
+
+
+@pytest.mark.gpu
+def test_bench_gpus_2_without_a_launcher_runs_two_ranks():
+    """The driver's launch form for N > 1 may be the plain `python bench.py --gpus N`: bench.py is then its own launcher.  Two
+    ranks share the test box's card over gloo (RCCL refuses that); the JSON line says who took part."""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--backend", "gloo", "--pairs", "20000", "--steps", "5",
+                        "--warmup", "2", "--gather-every", "2", "--no-cpu-baseline"], capture_output=True, text=True, timeout=900, env=env, cwd=ROOT)
+    assert p.returncode == 0, p.stderr[-3000:]
+    lines = [x for x in p.stdout.splitlines() if x.strip()]
+    assert len(lines) == 1, p.stdout
+    d = json.loads(lines[0])
+    g = d["config"]["gather"]
+    assert d["n_gpus"] == 2 and g["world"] == 2 and [r["rank"] for r in g["ranks"]] == [0, 1] and g["ranks"][0]["pid"] != g["ranks"][1]["pid"]
+    assert g["backend"].startswith("gloo") and d["cpu_baseline"] is None
 
 
 @pytest.mark.gpu
@@ -66,3 +95,4 @@ def test_bench_under_the_launcher_gathers_groups_of_steps(world, backend, extra)
     assert d["n_gpus"] == world and d["scaling"] == "weak" and d["value"] > 0
     g = d["config"]["gather"]
     assert g["steps_per_collective"] == int(extra[extra.index("--gather-every") + 1]) and g["cigar_bytes_per_rank_and_step"] > 0
+    assert g["world"] == world and len(g["ranks"]) == world and g["backend"].startswith("nccl (RCCL" if backend == "nccl" else "gloo")

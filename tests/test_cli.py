@@ -179,6 +179,54 @@ def test_cli_batch_gpus_n_matches_one_gpu(built, tmp_path, flags):
     assert p.returncode == 255 and b"first sequence must be shorter" in p.stderr
 
 
+@pytest.mark.gpu
+def test_cli_batch_streams_chunks_and_scales_all_vs_all(built, tmp_path):
+    """The batch driver parses, aligns and prints chunk by chunk: a run cut into chunks of 64 pairs prints the bytes of a run in
+    one chunk, with and without tracebacks.  And --all-vs-all --score-only over 3 000 reads (4.5 M pairs, slices streamed from
+    at_align_allpairs_stream, the triangle walked incrementally on the host) finishes in seconds -- its per-pair host work used
+    to be O(reads) -- with the oracle's scores on sampled lines."""
+    import time
+    import oracle as O
+    rng = random.Random(11)
+    with open(tmp_path / "pairs.fa", "w") as fh:
+        for k in range(1000):
+            a = "".join(rng.choice("ACGT") for _ in range(rng.randint(30, 120)))
+            b = "".join(rng.choice("ACGT") for _ in range(rng.randint(30, 120)))
+            fh.write(">p%da c\n%s\n>p%db\n%s\n" % (k, a, k, b))
+    for flags in ([], ["--score-only"]):
+        base = [EXE, "batch", "local", "-m", "2", "-u", "-2", "-o", "-5", "-e", "-2"] + flags + ["pairs.fa"]
+        one = subprocess.run(base, cwd=tmp_path, capture_output=True, timeout=600)
+        cut = subprocess.run(base, cwd=tmp_path, capture_output=True, timeout=600, env=dict(os.environ, AT_CLI_FIRST_CHUNK="64", AT_CLI_CHUNK="64"))
+        assert one.returncode == 0 and cut.returncode == 0, (one.stderr, cut.stderr)
+        assert one.stdout == cut.stdout and len(one.stdout.splitlines()) == (1000 if flags else 3000)
+    # an odd record at the end of a file of several chunks: the error still ends the run with the reference's rc
+    with open(tmp_path / "pairs.fa", "a") as fh:
+        fh.write(">odd\nACGT\n")
+    p = subprocess.run([EXE, "batch", "local", "pairs.fa"], cwd=tmp_path, capture_output=True, timeout=600, env=dict(os.environ, AT_CLI_FIRST_CHUNK="64", AT_CLI_CHUNK="64"))
+    assert p.returncode == 255 and b"even number of records (got 2001)" in p.stderr
+    p = subprocess.run([EXE, "batch", "local", "pairs.fa"], cwd=tmp_path, capture_output=True, timeout=600)
+    assert p.returncode == 255 and b"even number of records (got 2001)" in p.stderr and p.stdout == b""
+    # all-vs-all over 3 000 reads
+    n = 3000
+    reads = ["".join(rng.choice("ACGT") for _ in range(rng.randint(40, 60))) for _ in range(n)]
+    with open(tmp_path / "reads.fa", "w") as fh:
+        for k, r in enumerate(reads):
+            fh.write(">r%d\n%s\n" % (k, r))
+    t0 = time.time()
+    p = subprocess.run([EXE, "batch", "overlap", "--all-vs-all", "--score-only", "reads.fa"], cwd=tmp_path, capture_output=True, timeout=600,
+                       env=dict(os.environ, AT_CLI_CHUNK="1000000"))
+    dt = time.time() - t0
+    assert p.returncode == 0, p.stderr[-2000:]
+    lines = p.stdout.decode().splitlines()
+    assert len(lines) == n * (n - 1) // 2
+    assert dt < 60, dt
+    for q in [0, 1, n - 2, n - 1, 2 * n - 4, 1234567, len(lines) - 2, len(lines) - 1] + [rng.randrange(len(lines)) for _ in range(40)]:
+        a, b, sc = lines[q].split("\t")
+        ia, ib = int(a[1:]), int(b[1:])
+        assert ia < ib and ia * (2 * n - ia - 1) // 2 + (ib - ia - 1) == q, (q, a, b)
+        assert sc == "score=%f" % O.align(O.OVERLAP, reads[ia], reads[ib], 1, -2, -5, -1)["score"], (q, a, b)
+
+
 # ---------------------------------------------------------------- FASTA reader (CPU)
 class _Records(C.Structure):
     _fields_ = [("n", C.c_size_t), ("name", C.POINTER(C.c_char_p)), ("comment", C.POINTER(C.c_char_p)),

@@ -904,6 +904,64 @@ def test_all_vs_all_scores_long_reads(al):
     assert positive >= 5       # real overlaps are in the set
 
 
+def test_all_vs_all_streamed_in_slices(al):
+    """at_align_allpairs_stream: the triangle in slices with bounded memory.  The same pairs through slices of three different
+    sizes (one of them not dividing anything, one larger than the range) and through the single-shot device entry give the same
+    scores and end cells; a sub-range starts at the right pair; the callback sees every pair once, in order."""
+    import torch
+    import aligntools.c_amd as A
+    rng = random.Random(77)
+    n = 300
+    reads = [bytes(rng.choice(b"ACGT") for _ in range(rng.randint(60, 140))) for _ in range(n)]
+    lens = np.array([len(r) for r in reads], dtype=np.int32)
+    off = np.zeros(n, dtype=np.int64)
+    off[1:] = np.cumsum(lens[:-1])
+    blob = np.frombuffer(b"".join(reads) + b"\0", dtype=np.uint8).copy()
+    total = n * (n - 1) // 2
+    al.set_scoring(1, -2, -5, -1)
+
+    def run(first, npairs, chunk):
+        got = np.full((4, npairs), -12345, dtype=np.int32)
+        seen = []
+
+        def on_slice(f, sc, ei, ej, st):
+            seen.append((f, len(sc)))
+            for row, x in enumerate((sc, ei, ej, st)):
+                got[row, f - first:f - first + len(x)] = x
+        al.align_allpairs_stream("overlap", blob, off, lens, first, npairs, chunk, on_slice)
+        assert seen[0][0] == first and sum(x[1] for x in seen) == npairs
+        assert all(seen[k][0] + seen[k][1] == seen[k + 1][0] for k in range(len(seen) - 1))
+        return got, len(seen)
+    full, ns = run(0, total, 7001)
+    assert ns == (total + 7000) // 7001 and "slices" in al.last_config
+    for chunk in (1 << 20, 4096):
+        again, _ = run(0, total, chunk)
+        assert (again == full).all()
+    part, _ = run(12345, 20000, 3333)
+    assert (part == full[:, 12345:32345]).all()
+    # the single-shot device entry on the same reads
+    words, woff, _w2, l1, _l2, bits = A.pack_pairs([(r, b"") for r in reads])
+    dev = torch.device("cuda", 0)
+    d_words, d_woff, d_len = (torch.from_numpy(x).to(dev) for x in (words.view(np.int32), woff, l1))
+    res = torch.zeros((4, total), dtype=torch.int32, device=dev)
+    al.align_allpairs_device(A.MODE_OVERLAP, n, d_words.data_ptr(), bits, d_woff.data_ptr(), d_len.data_ptr(), int(lens.max()), 0, total, False,
+                             res[0].data_ptr(), res[1].data_ptr(), res[2].data_ptr(), res[3].data_ptr(), None, None, None,
+                             torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    assert (res.cpu().numpy()[:3] == full[:3]).all()
+    # and the oracle on a sample
+    for q in [0, total - 1] + [rng.randrange(total) for _ in range(60)]:
+        a = 0
+        while (a + 1) * (2 * n - a - 2) // 2 <= q:
+            a += 1
+        b = q - a * (2 * n - a - 1) // 2 + a + 1
+        ref = O.align(O.OVERLAP, reads[a], reads[b], 1, -2, -5, -1)
+        assert (int(full[0, q]), int(full[1, q]), int(full[2, q])) == (ref["score"], ref["end_i"], ref["end_j"]), (q, a, b)
+    # a callback that raises stops the sweep and surfaces in Python
+    with pytest.raises(ZeroDivisionError):
+        al.align_allpairs_stream("overlap", blob, off, lens, 0, total, 5000, lambda *a: 1 // 0)
+
+
 def test_bit_parallel_edit_distance(al):
     """`edit -u 1` (unit mismatch cost: Levenshtein) runs on the bit-parallel kernel (at_myers.hip.h): every word / lane
     boundary of l1 (32, 1024, 2048, 4096 rows), ragged and uniform batches, unrelated and related pairs, empty sequences,

@@ -126,6 +126,19 @@ def load_library():
     return lib
 
 
+def kernel_source_sha16():
+    """Fingerprint of the kernel sources (csrc/*.hip, *.hip.h, at_launch.h): the committed PMC counters under profiles/ belong to
+    one state of the kernels, and bench.py prices its roofline with them only while this fingerprint still matches."""
+    import hashlib
+    d = os.path.join(HERE, "csrc")
+    h = hashlib.sha256()
+    for name in sorted(os.listdir(d)):
+        if name.endswith((".hip", ".hip.h", ".h")):
+            h.update(name.encode() + b"\0")
+            h.update(open(os.path.join(d, name), "rb").read())
+    return h.hexdigest()[:16]
+
+
 class opt_t:
     """The reference's scoring block with its defaults (init_opt, alignment.h:102-114)."""
 

@@ -11,6 +11,9 @@
 #include "../../../include/aligntools_hip.h"
 
 #include <algorithm>
+#include <chrono>
+#include <condition_variable>
+#include <mutex>
 #include <cstdarg>
 #include <cstdio>
 #include <cstdlib>
@@ -43,6 +46,13 @@ struct at_handle {
 	void *d_str = nullptr; size_t str_bytes = 0;
 	void *d_scan = nullptr; size_t scan_bytes = 0;
 	int *d_rflag = nullptr;         /* at_render_k's "op list walks off its sequences" flag */
+	/* host entry: page-locked staging -- descriptor block, raw bytes on their way up, results and payload on their way down */
+	void *hp_desc = nullptr; size_t hp_desc_bytes = 0;
+	void *hp_blob = nullptr; size_t hp_blob_bytes = 0;
+	void *hp_out = nullptr; size_t hp_out_bytes = 0;
+	void *hp_flag = nullptr;
+	hipEvent_t ev_upload[16] = {};  /* ordered uploads of the chunks of a batch (UploadGate) */
+	double last_payload_per_pair = 16.0;   /* traceback bytes per pair of the latest batch: how much payload the next one fetches unasked */
 	/* all-vs-all in slices: a copy stream, pinned result buffers (two sets, used in turn) and their events */
 	hipStream_t copy_stream = nullptr;
 	void *h_pin = nullptr; size_t pin_bytes = 0;
@@ -104,6 +114,7 @@ extern "C" int at_init(const int *device_ids, int n_devices, at_handle **out)
 		HIP_TRY(h, hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
 		HIP_TRY(h, hipMalloc((void **)&h->d_rflag, 256));
 		HIP_TRY(h, hipMemset(h->d_rflag, 0, 256));
+		HIP_TRY(h, hipHostMalloc(&h->hp_flag, 256, hipHostMallocDefault));
 		return AT_OK;
 	};
 	const int rc = init();
@@ -142,6 +153,11 @@ extern "C" void at_destroy(at_handle *h)
 	if (h->d_scan) (void)hipFree(h->d_scan);
 	if (h->d_rflag) (void)hipFree(h->d_rflag);
 	if (h->h_pin) (void)hipHostFree(h->h_pin);
+	for (int q = 0; q < 16; ++q) if (h->ev_upload[q]) (void)hipEventDestroy(h->ev_upload[q]);
+	if (h->hp_desc) (void)hipHostFree(h->hp_desc);
+	if (h->hp_blob) (void)hipHostFree(h->hp_blob);
+	if (h->hp_out) (void)hipHostFree(h->hp_out);
+	if (h->hp_flag) (void)hipHostFree(h->hp_flag);
 	for (int q = 0; q < 2; ++q) {
 		if (h->ev_sweep[q]) (void)hipEventDestroy(h->ev_sweep[q]);
 		if (h->ev_copy[q]) (void)hipEventDestroy(h->ev_copy[q]);
@@ -325,7 +341,7 @@ struct Layout16 {
  * lanes (8 alignments per wave, 85 %; one group of 64 lanes: 59 %) and so do 209..304 bases with 16 / 19 rows per lane,
  * 305..608 bases as 2 groups of 32 lanes (10 .. 19 rows per lane), everything
  * else as one group of 64 lanes.  AT_GROUP = 8 / 16 / 32 / 64 caps the choice (A/B runs); ragged frames name their group width themselves. */
-static Layout16 layout16_for(bool tb, bool hasj, int l1, int l2, int ts, int force_g = 0, bool overlap = false, int kmode = -1)   /* force_g: 8 / 16 = ragged frames on that group width; 64 = tail */
+static Layout16 layout16_for(bool tb, bool hasj, int l1, int l2, int ts, int force_g = 0, bool overlap = false, int kmode = -1, int force_k = 0)   /* force_g: 8 / 16 = ragged frames on that group width; 64 = the 64-lane items behind a batch of narrow-group items, force_k rows per lane */
 {
 	Layout16 L;
 	const long long g_forced = env_ll("AT_GROUP", 0);
@@ -337,7 +353,13 @@ static Layout16 layout16_for(bool tb, bool hasj, int l1, int l2, int ts, int for
 	/* overlap (one state: few registers even with pointers): 4 or 16 rows per lane, whichever needs fewer instructions */
 	if (overlap) L.k = env_ll("AT_ROWS_PER_LANE", 0) == 4 ? 4 : ((l1 + 1023) / 1024) * (16 * 9 + 45) < ((l1 + 255) / 256) * (4 * 9 + 30) ? 16 : 4;
 	if (force_g == 64) {
-		/* the sliver of a batch behind its whole rounds (align_device): one group of 64 lanes, whatever the read length */
+		/* the sliver of a batch behind its whole rounds (align_device), ragged overlap: one group of 64 lanes, whatever the read length */
+		if (force_k) L.k = force_k;
+	} else if (force_g == 32) {
+		/* ragged frames of reads of 305 .. 608 bases, or (force_k) the sliver behind a batch of narrow-group items: one strip on two
+		 * groups of 32 lanes */
+		L.g = 32;
+		L.k = force_k ? force_k : l1 <= 320 ? 10 : l1 <= 384 ? 12 : l1 <= 416 ? 13 : l1 <= 512 ? 16 : 19;
 	} else if (!force_g && (g_forced == 0 || g_forced == 4) && ts == 4 && l1 <= 76) {
 		/* reads of up to 76 bases: sixteen groups of 4 lanes x 9 / 10 / 13 / 16 / 19 rows, 32 alignments per wave */
 		L.g = 4;
@@ -372,7 +394,11 @@ static Layout16 layout16_for(bool tb, bool hasj, int l1, int l2, int ts, int for
 	long long nref = (at::kPad + (long long)tbk * blk) / 4 + 4;
 	nref = (nref + 1) & ~1LL;
 	const long long nbound = 2LL * (l2 + 2);
-	const long long nptr = tb ? nstrips * tbk * (blk / (hasj ? 2 : 4)) * L.k * L.ptr_lanes + 64 : 0;
+	/* steps per pointer word (and alignment): 4-bit cells, 4; the jump state with scores x4 keeps byte cells, 2 -- with scores x16 it has
+	 * 4-bit cells plus a bit plane of one word per 4 rows x 4 steps behind the cells (at_sweep16.hip.h: JPL); packed overlap: 2-bit cells, 8 */
+	const int spw = overlap ? 16 / AT_OVL_BITS : (hasj && !(ts == 4 && AT_JPLANE)) ? 2 : 4;
+	const long long njpl = tb && hasj && ts == 4 && AT_JPLANE ? nstrips * tbk * (blk / 4) * ((L.k + 3) / 4) * L.ptr_lanes : 0;
+	const long long nptr = tb ? nstrips * tbk * (blk / spw) * L.k * L.ptr_lanes + njpl + 64 : 0;
 	const long long nsm = hasj ? (((long long)l2 + 64 + 64 + 128 + 31) / 32 + 2 + 1) & ~1LL : 0;
 	L.off_refb = (int)nref;
 	L.off_bound = (int)(2 * nref * ng);
@@ -425,7 +451,7 @@ static int choose_store(long long words_fixed, long long words_ptr, bool prefer_
 /* is there a packed instantiation for the storage class plan_launch will choose for this layout? */
 static bool packed16_kernel_exists(int kmode, const Layout16 &P, bool tb, int ts, int bits, int rag)
 {
-	const int st = choose_store(P.off_ptr, P.words - P.off_ptr, P.g < 64);
+	const int st = choose_store(P.off_ptr, P.words - P.off_ptr, P.g < 64 || rag);   /* (ragged frames exist with the pointers in the global slots only) */
 	if (P.g != 64 && st == 2) return false;
 	return (rag ? at_pick16_rag(kmode, P.g, P.k, st, tb, bits) : at_pick16(kmode, P.g, P.k, ts, st, tb, bits)) != nullptr;
 }
@@ -437,6 +463,18 @@ static int grow(at_handle *h, void **p, size_t *have, size_t need)
 	need = need + need / 8 + 4096;
 	hipError_t e = hipMalloc(p, need);
 	if (e != hipSuccess) return fail(h, AT_ERR_NOMEM, "hipMalloc(%zu): %s", need, hipGetErrorString(e));
+	*have = need;
+	return AT_OK;
+}
+
+/* page-locked host memory, grow-only */
+static int grow_pinned(at_handle *h, void **p, size_t *have, size_t need)
+{
+	if (need <= *have) return AT_OK;
+	if (*p) { (void)hipHostFree(*p); *p = nullptr; *have = 0; }
+	need = need + need / 4 + 4096;
+	hipError_t e = hipHostMalloc(p, need, hipHostMallocDefault);
+	if (e != hipSuccess) return fail(h, AT_ERR_NOMEM, "hipHostMalloc(%zu): %s", need, hipGetErrorString(e));
 	*have = need;
 	return AT_OK;
 }
@@ -553,7 +591,7 @@ static int align_device(at_handle *h, int mode, int64_t npairs,
                         int32_t *d_score, int32_t *d_end_i, int32_t *d_end_j, int32_t *d_state,
                         uint8_t *d_ops, const int64_t *d_ops_off, int32_t *d_nops, void *stream_,
                         int64_t ap_n, int64_t ap_first, const int *d_order = nullptr, int rag = 0,
-                        const int *only_if = nullptr, int only_val = 0, int tail = 0);
+                        const int *only_if = nullptr, int only_val = 0);
 
 extern "C" int at_align_batch_device(at_handle *h, int mode, int64_t npairs,
                                      const uint32_t *d_seq, int bits,
@@ -661,7 +699,7 @@ static int align_device(at_handle *h, int mode, int64_t npairs,
                         int32_t max_len1, int32_t max_len2, int uniform_shape, int want_traceback,
                         int32_t *d_score, int32_t *d_end_i, int32_t *d_end_j, int32_t *d_state,
                         uint8_t *d_ops, const int64_t *d_ops_off, int32_t *d_nops, void *stream_,
-                        int64_t ap_n, int64_t ap_first, const int *d_order, int rag, const int *only_if, int only_val, int tail)
+                        int64_t ap_n, int64_t ap_first, const int *d_order, int rag, const int *only_if, int only_val)
 {
 	if (!h) return fail(nullptr, AT_ERR_ARG, "at_align_batch_device: NULL handle");
 	if (mode < AT_MODE_GLOBAL || mode > AT_MODE_EDIT) return fail(h, AT_ERR_ARG, "unknown mode %d", mode);
@@ -714,20 +752,21 @@ static int align_device(at_handle *h, int mode, int64_t npairs,
 	}
 	if ((uniform_shape || rag) && ap_n == 0) {
 		if (packed_ok(h, mode, bits, max_len1, max_len2, 4, &thresh16)) ts = 4;
-		else if (!rag && packed_ok(h, mode, bits, max_len1, max_len2, 2, &thresh16)) ts = 2;
+		else if ((!rag || kmode == at::K_OVERLAP) && packed_ok(h, mode, bits, max_len1, max_len2, 2, &thresh16)) ts = 2;
 		/* overlap: the packed kernel exists with pointers only (scores alone: the int32 kernel's 3 instructions per cell win) */
 		if (kmode == at::K_OVERLAP && (!tb || getenv("AT_NO_PACKED_OVERLAP"))) ts = 0;
 	}
-	if (rag && (!ts || kmode > at::K_FITJ || max_len1 > (rag == 8 ? 152 : 304) || !d_order))
+	if (rag && (!ts || (kmode > at::K_FITJ && !(kmode == at::K_OVERLAP && rag == 64)) || max_len1 > (rag == 8 ? 152 : rag == 16 ? 304 : rag == 32 ? 608 : 1024) || !d_order))
 		return fail(h, AT_ERR_ARG, "ragged packed launch outside its domain");   /* the host entry checks before it asks */
 	Layout16 P;
 	if (ts) {
-		P = layout16_for(tb, kmode == at::K_FITJ, max_len1, max_len2, ts, tail ? 64 : rag, kmode == at::K_OVERLAP, kmode);
+		P = layout16_for(tb, kmode == at::K_FITJ, max_len1, max_len2, ts, rag, kmode == at::K_OVERLAP, kmode,
+		                 rag && kmode == at::K_OVERLAP ? (max_len1 <= 256 ? 4 : 16) : 0);   /* (ragged overlap: one strip) */
 		/* A 64-lane packed wave carries 2 alignments where an int32 wave carries 1: fewer, longer work items.  A batch
 		 * that cannot give every resident wave one of them stays on the int32 kernel.  (10k x 1024^2 = 1.6 rounds: 1.96
 		 * packed vs 2.00 TCUPS int32 for a lone launch, 2.70 vs 2.13 with launches in flight; 61k pairs: 2.70 vs 2.19.) */
 		const double min_rounds = getenv("AT_PACKED_MIN_ROUNDS") ? atof(getenv("AT_PACKED_MIN_ROUNDS")) : 1.0;
-		if (P.g == 64 && !tail && (double)((npairs + 1) / 2) < min_rounds * 12.0 * h->ncu) ts = 0;
+		if (P.g == 64 && (double)((npairs + 1) / 2) < min_rounds * 12.0 * h->ncu) ts = 0;
 		/* the packed kernels index their slot with 24-bit multiplies: a pair whose slot would not fit takes the int32 kernel */
 		if (P.words >= (1LL << 24)) { if (rag) return fail(h, AT_ERR_ARG, "ragged packed launch outside its domain (slot too large)"); ts = 0; }
 		/* no packed kernel for the storage class this shape needs (the 16- and 32-lane groups have no all-HBM variant:
@@ -763,40 +802,51 @@ static int align_device(at_handle *h, int mode, int64_t npairs,
 		         rag ? " ragged frames" : "");
 		auto pick = [&](int st) { return rag ? at_pick16_rag(kmode, P.g, P.k, st, tb, bits) : at_pick16(kmode, P.g, P.k, ts, st, tb, bits); };
 		const long long nwork = (npairs + per_wave - 1) / per_wave;
-		int rc = plan_launch(h, tag16, P.k, nwork, P.off_ptr, P.words - P.off_ptr, &pl, stream,
-		                     [&](int st) { return (const void *)pick(st); }, P.g < 64);
+		/* The grid is the resident waves, each pulling work items until none are left.  A SIMD holds two of these waves and finishes
+		 * an item every ~118 us: C2's 6 250 items of 16 pairs on 1 024 SIMDs are 6.1 items per SIMD, so a launch that has the chip to
+		 * itself ends with 106 SIMDs working through a 7th item while the others idle (0.86 ms instead of 0.72).  When such a sliver
+		 * remains (the last round less than a quarter full), its pairs become items of two 32-lane groups -- four alignments per wave,
+		 * items a third as long -- that follow the main items IN THE SAME LAUNCH and work queue (the kernel's second argument,
+		 * at_sweep16.hip.h).  AT_TAIL_SPLIT=0: off.  (Round 2 ran the sliver as a second launch behind the
+		 * main one, which cost a caller who keeps launches in flight 8 %; round 3 first tried it on a stream of its own beside the
+		 * main launch: +6.5 % alone, -8 % in flight -- the next batch's waves took the slots the sliver was waiting for.) */
+		const bool tail_ok = !rag && !only_if && P.g <= 16 && kmode != at::K_OVERLAP && env_ll("AT_TAIL_SPLIT", 1);
+		Layout16 PT = P;
+		if (tail_ok) PT = layout16_for(tb, kmode == at::K_FITJ, max_len1, max_len2, ts, at::AT_TAIL_G, false, kmode, at::at_tail_k(P.g, P.k));
+		/* (the sliver's items use the main items' LDS window and pointer slot: both hold either layout -- the main items' are the larger) */
+		int rc = plan_launch(h, tag16, P.k, nwork, std::max(P.off_ptr, PT.off_ptr), std::max(P.words - P.off_ptr, PT.words - PT.off_ptr), &pl, stream,
+		                     [&](int st) { return (const void *)pick(st); }, P.g < 64 || rag);
 		if (rc) return rc;
-		/* The grid is the resident waves, each pulling work items until none are left: a batch of 3.05 rounds (C2: 6 250 items of
-		 * 16 pairs on 2 048 waves) ends with a round in which 5 % of the waves work and the rest of the chip waits a whole item
-		 * time for them.  AT_TAIL_SPLIT=1: when such a sliver remains, the main launch takes the whole rounds and the sliver goes
-		 * to the 64-lane kernel behind it -- two alignments per wave, items an eighth as long, enough of them to fill the chip.
-		 * Off by default: it helps a caller who waits for each launch (C2 one launch at a time 2 263 -> 2 367 GCUPS, scores only
-		 * 3 867 -> 4 009) and costs one who keeps launches in flight, where the next launch fills the idle SIMDs anyway and the
-		 * second launch is pure overhead (C2 on 3 streams 2 921 -> 2 699; C4 2 058 -> 2 018).  profiles/r02/ab_tail_split.json */
 		int64_t n_tail = 0;
-		if (!tail && !rag && !only_if && P.g <= 16 && nwork > pl.grid && env_ll("AT_TAIL_SPLIT", 0)) {
+		if (tail_ok && nwork > pl.grid) {
 			const long long sliver = nwork % pl.grid;
-			if (sliver > 0 && sliver * 3 <= pl.grid) {
-				n_tail = npairs - (nwork - sliver) * per_wave;
-				b.npairs = npairs - n_tail;
-			}
+			if (sliver > 0 && sliver * 4 <= pl.grid) n_tail = npairs - (nwork - sliver) * per_wave;   /* (four 32-lane items per 8-lane item: one per SIMD at most) */
+		}
+		Sweep16Args bt = b;
+		bt.npairs = 0;
+		if (n_tail > 0) {
+			const int64_t nm = npairs - n_tail;
+			b.npairs = nm;
+			bt.npairs = n_tail;
+			bt.woff1 += nm; bt.woff2 += nm; bt.len1 += nm; bt.len2 += nm;
+			bt.score += nm;
+			if (bt.end_i) bt.end_i += nm;
+			if (bt.end_j) bt.end_j += nm;
+			if (bt.state) bt.state += nm;
+			if (bt.ops_off) bt.ops_off += nm;
+			if (bt.nops) bt.nops += nm;
+			bt.off_refb = PT.off_refb; bt.off_bound = PT.off_bound; bt.ptr_lanes = PT.ptr_lanes; bt.off_sm = PT.off_sm; bt.nsm = PT.nsm;
 		}
 		b.off_ptr = pl.off_ptr; b.ws = pl.ws; b.ws_slot_words = pl.slot_words; b.queue = h->d_queue;
+		bt.off_ptr = pl.store == 1 ? 0 : PT.off_ptr; bt.ws = pl.ws; bt.ws_slot_words = pl.slot_words; bt.queue = h->d_queue;
 		at_sweep16_fn fn16 = pick(pl.store);
 		if (!fn16 || (P.g != 64 && pl.store == 2)) return fail(h, AT_ERR_RANGE, "no packed kernel for this shape (rows/lane=%d, store=%d)", P.k, pl.store);
 		if (pl.dyn_lds > 48 * 1024)
 			HIP_TRY(h, hipFuncSetAttribute((const void *)fn16, hipFuncAttributeMaxDynamicSharedMemorySize, (int)pl.dyn_lds));
-		hipLaunchKernelGGL(fn16, dim3((unsigned)pl.grid), dim3(64), pl.dyn_lds, stream, b);
+		hipLaunchKernelGGL(fn16, dim3((unsigned)pl.grid), dim3(64), pl.dyn_lds, stream, b, bt);
 		HIP_TRY(h, hipGetLastError());
-		if (n_tail > 0) {
-			const int64_t nm = npairs - n_tail;
-			const std::string main_cfg = h->cfg;
-			rc = align_device(h, mode, n_tail, d_seq, bits, d_woff1 + nm, d_len1 + nm, d_woff2 + nm, d_len2 + nm, max_len1, max_len2, 1, want_traceback,
-			                  d_score + nm, d_end_i ? d_end_i + nm : nullptr, d_end_j ? d_end_j + nm : nullptr, d_state ? d_state + nm : nullptr,
-			                  d_ops, d_ops_off ? d_ops_off + nm : nullptr, d_nops ? d_nops + nm : nullptr, stream_, 0, 0, nullptr, 0, nullptr, 0, 1);
-			if (rc) return rc;
-			snprintf(h->cfg, sizeof h->cfg, "%.230s + last %lld pairs on 64-lane groups", main_cfg.c_str(), (long long)n_tail);
-		}
+		if (n_tail > 0)
+			snprintf(h->cfg + strlen(h->cfg), sizeof h->cfg - strlen(h->cfg), " + last %lld pairs as 32-lane items (rows/lane=%d)", (long long)n_tail, PT.k);
 		return AT_OK;
 	}
 
@@ -868,6 +918,28 @@ static int align_device(at_handle *h, int mode, int64_t npairs,
 	return AT_OK;
 }
 
+/* The chunks of one batch upload IN ORDER: chunk c's copies are queued (on its own stream) behind an event that marks the end of
+ * chunk c - 1's, so every chunk crosses the link at its full rate and the first chunk's sweep runs while the others still upload --
+ * side by side all uploads end together, late, and all sweeps start then.  The staging copies into page-locked memory before that
+ * run on the chunks' threads, in parallel. */
+struct UploadGate {
+	std::mutex mu;
+	std::condition_variable cv;
+	int next = 0;                   /* the chunk whose turn it is to queue its uploads */
+	hipEvent_t done[16] = {};       /* chunk c's uploads have arrived */
+	bool failed = false;
+};
+
+/* AT_HOST_TRACE=1: microseconds since the first call at the stages of the host entry, on stderr (where does a call's time go?) */
+static void htrace(const char *what, long long a)
+{
+	static const bool on = getenv("AT_HOST_TRACE") != nullptr;
+	if (!on) return;
+	static const auto t0 = std::chrono::steady_clock::now();
+	const double us = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count();
+	fprintf(stderr, "[host %10.1f us] %s %lld\n", us, what, a);
+}
+
 /* host-buffer entry; with out_r1/out_r2 the strings are rendered on the GPU (slots of len1+len2+1 bytes at ops_off[k])
  * and the op codes stay on the device */
 static int align_host(at_handle *h, int mode, int64_t npairs, const uint8_t *seq_blob,
@@ -875,8 +947,15 @@ static int align_host(at_handle *h, int mode, int64_t npairs, const uint8_t *seq
                       int want_traceback,
                       int32_t *out_score, int32_t *out_end_i, int32_t *out_end_j, int32_t *out_state,
                       uint8_t *out_ops, const int64_t *ops_off, int32_t *out_nops, char *out_r1, char *out_r2,
-                      int64_t pair_base = 0)   /* index of pair 0 in the caller's batch, for messages */
+                      int64_t pair_base = 0,   /* index of pair 0 in the caller's batch, for messages */
+                      UploadGate *gate = nullptr, int gate_index = 0)
 {
+	/* (whatever happens, the chunks behind this one must get their turn) */
+	struct Turn {
+		UploadGate *g; int idx; bool passed = false;
+		void pass() { if (g && !passed) { std::lock_guard<std::mutex> lk(g->mu); g->next = std::max(g->next, idx + 1); passed = true; g->cv.notify_all(); } }
+		~Turn() { pass(); }
+	} turn{gate, gate_index};
 	if (!h) return fail(nullptr, AT_ERR_ARG, "at_align_batch: NULL handle");
 	if (mode < AT_MODE_GLOBAL || mode > AT_MODE_EDIT) return fail(h, AT_ERR_ARG, "unknown mode %d", mode);
 	if (npairs < 0) return fail(h, AT_ERR_ARG, "negative npairs");
@@ -908,89 +987,101 @@ static int align_host(at_handle *h, int mode, int64_t npairs, const uint8_t *seq
 		if (off1[k] < 0 || off2[k] < 0) return fail(h, AT_ERR_ARG, "pair %lld: negative sequence offset", (long long)(pair_base + k));
 		blob_lo = std::min<int64_t>(blob_lo, std::min(off1[k], off2[k]));
 	}
+	htrace("chunk: lengths checked, pair", pair_base);
 	/* only the span of the blob and of the ops buffer that this call touches travels (a chunk of a larger batch,
 	 * see at_align_batch, addresses the caller's buffers with absolute offsets) */
 	if (!tb) ops_lo = 0;
 	ops_total -= ops_lo;
 	HIP_TRY(h, hipSetDevice(h->device));
 
-	/* ---- inputs go up RAW; packing happens on the GPU (at_pack.hip.h).  Host work is O(npairs): word offsets. ---- */
-	std::vector<int64_t> soff((size_t)2 * npairs), swoff2((size_t)2 * npairs), swoff8((size_t)2 * npairs);
-	std::vector<int32_t> slen((size_t)2 * npairs);
+	/* ---- inputs go up RAW; packing happens on the GPU (at_pack.hip.h).  Host work is O(npairs): one pass writes every descriptor
+	 * ---- array into ONE page-locked block that mirrors the device block, so all of them travel in one copy; the raw bytes are
+	 * ---- staged through page-locked memory in pieces by this thread (the chunks of a batch run on threads of their own: their
+	 * ---- staging copies run side by side, where the runtime's own pageable path took them one after the other) ---- */
+	auto al = [](size_t x) { return (x + 255) & ~(size_t)255; };
+	const size_t n = (size_t)npairs;
+	/* descriptor block: soff[2n] swoff2[2n] swoff8[2n] opsoff[n] woff1_2[n] woff2_2[n] woff1_8[n] woff2_8[n] (int64) slen[2n] len1[n] len2[n] (int32) */
+	const size_t o_soff = 0, o_sw2 = o_soff + al(2 * n * 8), o_sw8 = o_sw2 + al(2 * n * 8), o_ops = o_sw8 + al(2 * n * 8);
+	const size_t o_w12 = o_ops + al(n * 8), o_w22 = o_w12 + al(n * 8), o_w18 = o_w22 + al(n * 8), o_w28 = o_w18 + al(n * 8);
+	const size_t o_slen = o_w28 + al(n * 8), o_l1 = o_slen + al(2 * n * 4), o_l2 = o_l1 + al(n * 4), desc_bytes = o_l2 + al(n * 4);
+	int rc = grow_pinned(h, &h->hp_desc, &h->hp_desc_bytes, desc_bytes);
+	if (rc) return rc;
+	char *hd = (char *)h->hp_desc;
+	int64_t *p_soff = (int64_t *)(hd + o_soff), *p_sw2 = (int64_t *)(hd + o_sw2), *p_sw8 = (int64_t *)(hd + o_sw8), *p_ops = (int64_t *)(hd + o_ops);
+	int64_t *p_w12 = (int64_t *)(hd + o_w12), *p_w22 = (int64_t *)(hd + o_w22), *p_w18 = (int64_t *)(hd + o_w18), *p_w28 = (int64_t *)(hd + o_w28);
+	int32_t *p_slen = (int32_t *)(hd + o_slen), *p_l1 = (int32_t *)(hd + o_l1), *p_l2 = (int32_t *)(hd + o_l2);
 	int64_t nwords2 = 0, nwords8 = 0, blob_bytes = 0;
 	for (int64_t k = 0; k < npairs; ++k) {
-		soff[2 * k] = off1[k] - blob_lo; slen[2 * k] = len1[k];
-		soff[2 * k + 1] = off2[k] - blob_lo; slen[2 * k + 1] = len2[k];
-		for (int q = 0; q < 2; ++q) {
-			const int len = slen[2 * k + q];
-			swoff2[2 * k + q] = nwords2; nwords2 += (len + 15) / 16 + 1;
-			swoff8[2 * k + q] = nwords8; nwords8 += (len + 3) / 4 + 1;
-			blob_bytes = std::max<int64_t>(blob_bytes, soff[2 * k + q] + len);
-		}
+		const int a1 = len1[k], a2 = len2[k];
+		p_soff[2 * k] = off1[k] - blob_lo; p_soff[2 * k + 1] = off2[k] - blob_lo;
+		p_slen[2 * k] = a1; p_slen[2 * k + 1] = a2;
+		p_l1[k] = a1; p_l2[k] = a2;
+		p_sw2[2 * k] = p_w12[k] = nwords2; nwords2 += (a1 + 15) / 16 + 1;
+		p_sw2[2 * k + 1] = p_w22[k] = nwords2; nwords2 += (a2 + 15) / 16 + 1;
+		p_sw8[2 * k] = p_w18[k] = nwords8; nwords8 += (a1 + 3) / 4 + 1;
+		p_sw8[2 * k + 1] = p_w28[k] = nwords8; nwords8 += (a2 + 3) / 4 + 1;
+		blob_bytes = std::max<int64_t>(blob_bytes, std::max(p_soff[2 * k] + a1, p_soff[2 * k + 1] + a2));
+		if (tb) p_ops[k] = ops_off[k] - ops_lo;
 	}
-	auto al = [](size_t x) { return (x + 255) & ~(size_t)255; };
 	const bool force8 = !scores_fit_byte(h, mode);    /* large scores: byte-compare kernels */
 	const int64_t nwords_max = std::max(nwords2, nwords8) + 4;
-	/* device input block: words | seq off | seq woff | seq len | ops_off | flag | raw blob */
-	const size_t b_words = al((size_t)nwords_max * 4), b_off = al((size_t)2 * npairs * 8), b_len = al((size_t)2 * npairs * 4);
-	const size_t b_blob = al((size_t)blob_bytes + 16);
-	const size_t in_need = b_words + 3 * b_off + b_len + 256 + b_blob;
-	int rc = grow(h, &h->d_in, &h->in_bytes, in_need);
+	/* device input block: words | descriptor block | flag | raw blob */
+	const size_t b_words = al((size_t)nwords_max * 4), b_blob = al((size_t)blob_bytes + 16);
+	rc = grow(h, &h->d_in, &h->in_bytes, b_words + desc_bytes + 256 + b_blob);
 	if (rc) return rc;
-	char *din = (char *)h->d_in;
+	char *din = (char *)h->d_in, *dd = din + b_words;
 	uint32_t *d_words = (uint32_t *)din;
-	int64_t *d_soff = (int64_t *)(din + b_words), *d_swoff = (int64_t *)(din + b_words + b_off);
-	int64_t *d_opsoff = (int64_t *)(din + b_words + 2 * b_off);
-	int32_t *d_slen = (int32_t *)(din + b_words + 3 * b_off);
-	int *d_flag = (int *)(din + b_words + 3 * b_off + b_len);
-	uint8_t *d_blob = (uint8_t *)(din + b_words + 3 * b_off + b_len + 256);
+	int64_t *d_soff = (int64_t *)(dd + o_soff), *d_opsoff = (int64_t *)(dd + o_ops);
+	int32_t *d_slen = (int32_t *)(dd + o_slen), *d_len1 = (int32_t *)(dd + o_l1), *d_len2 = (int32_t *)(dd + o_l2);
+	int *d_flag = (int *)(dd + desc_bytes);
+	uint8_t *d_blob = (uint8_t *)(dd + desc_bytes + 256);
 	hipStream_t s = h->stream;
-	HIP_TRY(h, hipMemcpyAsync(d_blob, seq_blob + blob_lo, (size_t)blob_bytes, hipMemcpyHostToDevice, s));
-	HIP_TRY(h, hipMemcpyAsync(d_soff, soff.data(), (size_t)2 * npairs * 8, hipMemcpyHostToDevice, s));
-	HIP_TRY(h, hipMemcpyAsync(d_slen, slen.data(), (size_t)2 * npairs * 4, hipMemcpyHostToDevice, s));
-	std::vector<int64_t> opsr;
-	if (tb) {
-		opsr.resize((size_t)npairs);
-		for (int64_t k = 0; k < npairs; ++k) opsr[(size_t)k] = ops_off[k] - ops_lo;
-		HIP_TRY(h, hipMemcpyAsync(d_opsoff, opsr.data(), (size_t)npairs * 8, hipMemcpyHostToDevice, s));
+	rc = grow_pinned(h, &h->hp_blob, &h->hp_blob_bytes, (size_t)blob_bytes + 64);
+	if (rc) return rc;
+	if (gate) {
+		/* stage everything, wait for this chunk's turn, queue the copies behind the previous chunk's */
+		memcpy(h->hp_blob, seq_blob + blob_lo, (size_t)blob_bytes);
+		htrace("chunk: staged, pair", pair_base);
+		{
+			std::unique_lock<std::mutex> lk(gate->mu);
+			gate->cv.wait(lk, [&] { return gate->next >= gate_index; });
+		}
+		if (gate_index > 0) HIP_TRY(h, hipStreamWaitEvent(s, gate->done[gate_index - 1], 0));
+		HIP_TRY(h, hipMemcpyAsync(dd, hd, desc_bytes, hipMemcpyHostToDevice, s));
+		HIP_TRY(h, hipMemcpyAsync(d_blob, h->hp_blob, (size_t)blob_bytes, hipMemcpyHostToDevice, s));
+		HIP_TRY(h, hipEventRecord(gate->done[gate_index], s));
+		turn.pass();
+	} else {
+		HIP_TRY(h, hipMemcpyAsync(dd, hd, desc_bytes, hipMemcpyHostToDevice, s));
+		const size_t piece = (size_t)env_ll("AT_HOST_STAGE_PIECE", 1 << 20);
+		for (size_t at = 0; at < (size_t)blob_bytes; at += piece) {   /* (one chunk: the staging of a piece beside the transfer of the one before) */
+			const size_t nb = std::min(piece, (size_t)blob_bytes - at);
+			memcpy((char *)h->hp_blob + at, seq_blob + blob_lo + at, nb);
+			HIP_TRY(h, hipMemcpyAsync(d_blob + at, (char *)h->hp_blob + at, nb, hipMemcpyHostToDevice, s));
+		}
 	}
 	at::PackArgs pa;
 	pa.nseq = 2 * npairs; pa.blob = d_blob; pa.off = (const long long *)d_soff; pa.len = d_slen;
-	pa.woff = (const long long *)d_swoff; pa.words = d_words; pa.not_acgt = d_flag;
+	pa.words = d_words; pa.not_acgt = d_flag;
 	const unsigned pgrid = (unsigned)std::min<int64_t>((2 * npairs + 3) / 4, 8LL * h->ncu);
 	int bits = force8 ? 8 : 2;
-	int flag = 0;
+	int *p_flag = (int *)((char *)h->hp_flag);
 	if (bits == 2) {
 		HIP_TRY(h, hipMemsetAsync(d_flag, 0, 4, s));
-		HIP_TRY(h, hipMemcpyAsync(d_swoff, swoff2.data(), (size_t)2 * npairs * 8, hipMemcpyHostToDevice, s));
+		pa.woff = (const long long *)(dd + o_sw2);
 		hipLaunchKernelGGL(at::at_pack<2>, dim3(pgrid), dim3(256), 0, s, pa);
-		HIP_TRY(h, hipMemcpyAsync(&flag, d_flag, 4, hipMemcpyDeviceToHost, s));
+		HIP_TRY(h, hipMemcpyAsync(p_flag, d_flag, 4, hipMemcpyDeviceToHost, s));
+		htrace("chunk: uploads and packing queued, pair", pair_base);
 		HIP_TRY(h, hipStreamSynchronize(s));
-		if (flag) bits = 8;                            /* some byte is not one of ACGT: byte kernels */
+		htrace("chunk: packed, pair", pair_base);
+		if (*p_flag) bits = 8;                         /* some byte is not one of ACGT: byte kernels */
 	}
 	if (bits == 8) {
-		HIP_TRY(h, hipMemcpyAsync(d_swoff, swoff8.data(), (size_t)2 * npairs * 8, hipMemcpyHostToDevice, s));
+		pa.woff = (const long long *)(dd + o_sw8);
 		hipLaunchKernelGGL(at::at_pack<8>, dim3(pgrid), dim3(256), 0, s, pa);
 	}
 	HIP_TRY(h, hipGetLastError());
-	/* the sweep kernels take per-pair arrays: views with stride 2 are not possible, so de-interleave on the host side
-	 * of the descriptor block (tiny) */
-	std::vector<int64_t> woff1((size_t)npairs), woff2((size_t)npairs);
-	{
-		const std::vector<int64_t> &sw = bits == 2 ? swoff2 : swoff8;
-		for (int64_t k = 0; k < npairs; ++k) { woff1[(size_t)k] = sw[2 * k]; woff2[(size_t)k] = sw[2 * k + 1]; }
-	}
-	const size_t b_poff = al((size_t)npairs * 8), b_plen = al((size_t)npairs * 4);
-	rc = grow(h, &h->d_desc, &h->desc_bytes, 2 * b_poff + 2 * b_plen);
-	if (rc) return rc;
-	char *dd = (char *)h->d_desc;
-	int64_t *d_woff1 = (int64_t *)dd, *d_woff2 = (int64_t *)(dd + b_poff);
-	int32_t *d_len1 = (int32_t *)(dd + 2 * b_poff), *d_len2 = (int32_t *)(dd + 2 * b_poff + b_plen);
-	HIP_TRY(h, hipMemcpyAsync(d_woff1, woff1.data(), (size_t)npairs * 8, hipMemcpyHostToDevice, s));
-	HIP_TRY(h, hipMemcpyAsync(d_woff2, woff2.data(), (size_t)npairs * 8, hipMemcpyHostToDevice, s));
-	HIP_TRY(h, hipMemcpyAsync(d_len1, len1, (size_t)npairs * 4, hipMemcpyHostToDevice, s));
-	HIP_TRY(h, hipMemcpyAsync(d_len2, len2, (size_t)npairs * 4, hipMemcpyHostToDevice, s));
-	HIP_TRY(h, hipStreamSynchronize(s));   /* woff1/woff2 are stack-lifetime vectors */
+	int64_t *d_woff1 = (int64_t *)(dd + (bits == 2 ? o_w12 : o_w18)), *d_woff2 = (int64_t *)(dd + (bits == 2 ? o_w22 : o_w28));
 	const size_t b_len1 = al((size_t)npairs * 4);
 	/* device output block: score | end_i | end_j | state | nops | ops */
 	const size_t b_ops = al((size_t)ops_total + 64), b_pfx = al((size_t)(npairs + 1) * 8);
@@ -1022,42 +1113,53 @@ static int align_host(at_handle *h, int mode, int64_t npairs, const uint8_t *seq
 		int th = 0, min1 = INT32_MAX, min2 = INT32_MAX;
 		for (int64_t k = 0; k < npairs; ++k) { min1 = std::min(min1, len1[k]); min2 = std::min(min2, len2[k]); }
 		const bool affine = mode == AT_MODE_LOCAL || mode == AT_MODE_GLOBAL || mode == AT_MODE_FIT;
-		const int kmode_f = mode == AT_MODE_LOCAL ? at::K_LOCAL : mode == AT_MODE_GLOBAL ? at::K_GLOBAL : h->use_jump ? at::K_FITJ : at::K_FIT;
-		frames = affine && max1 <= 304 && min1 >= 1 && min2 >= 1 && npairs >= 64 && env_ll("AT_RAGGED_PACKED", 1) &&
-		         packed_ok(h, mode, bits, max1, max2, 4, &th);
-		/* every frame is at most max1 x max2: if that one has no packed kernel (s2 too long for LDS), none is tried */
+		const bool ovl = mode == AT_MODE_OVERLAP && tb;
+		const int kmode_f = mode == AT_MODE_LOCAL ? at::K_LOCAL : mode == AT_MODE_GLOBAL ? at::K_GLOBAL : mode == AT_MODE_OVERLAP ? at::K_OVERLAP
+		                  : h->use_jump ? at::K_FITJ : at::K_FIT;
+		/* the longest read with a one-strip frame: 32 lanes x 19 rows for local, x 16 for global, x 13 for fit (the uniform kernels'
+		 * classes, layout16_for); overlap: 64 lanes x 16 rows */
+		const int max_rag = mode == AT_MODE_LOCAL ? 608 : mode == AT_MODE_GLOBAL ? 512 : mode == AT_MODE_FIT ? 416 : 1024;
+		frames = (affine || ovl) && max1 <= max_rag && min1 >= 1 && min2 >= 1 && npairs >= 64 && env_ll("AT_RAGGED_PACKED", 1) &&
+		         packed_ok(h, mode, bits, max1, max2, ovl ? 2 : 4, &th);
+		/* (group width, rows per lane) of a read length.  Local frames mix read lengths freely and run on the 16-lane groups up to
+		 * 304 bases (on the 8-lane groups, whose lanes carry up to 19 rows, the same batches ran 15 % slower: 100..150 x 100..150 2.9
+		 * against 2.5 ms per 100k pairs), on the 32-lane groups beyond; global / fit: 8-lane groups up to 152 bases, 16-lane up to
+		 * 304, 32-lane beyond; overlap: the 64-lane group with 4 rows per lane up to 256 bases, 16 beyond */
+		auto gclass = [&](int l1) { return ovl ? 64 : l1 > 304 ? 32 : mode == AT_MODE_LOCAL ? 16 : l1 <= 152 ? 8 : 16; };
+		auto kclass = [&](int l1) {
+			if (ovl) return l1 <= 256 ? 4 : 16;
+			if (l1 > 304) return l1 <= 320 ? 10 : l1 <= 384 ? 12 : l1 <= 416 ? 13 : l1 <= 512 ? 16 : 19;
+			if (mode == AT_MODE_LOCAL) return l1 <= 64 ? 4 : l1 <= 80 ? 5 : l1 <= 96 ? 6 : l1 <= 112 ? 7 : l1 <= 160 ? 10 : l1 <= 208 ? 13 : l1 <= 256 ? 16 : 19;
+			return l1 <= 40 ? 5 : l1 <= 48 ? 6 : l1 <= 56 ? 7 : l1 <= 64 ? 8 : l1 <= 80 ? 10 : l1 <= 104 ? 13 : l1 <= 128 ? 16 : l1 <= 152 ? 19 : l1 <= 160 ? 10 : l1 <= 208 ? 13 : l1 <= 256 ? 16 : 19;
+		};
+		/* every frame is at most max1 x max2: if a class has no packed kernel for that (s2 too long for LDS), none is tried */
 		if (frames) {
 			const bool hasj = kmode_f == at::K_FITJ;
-			if (mode == AT_MODE_LOCAL || max1 > 152)
-				frames = packed16_kernel_exists(kmode_f, layout16_for(tb, hasj, max1, max2, 4, 16), tb, 4, bits, 16);
-			if (frames && mode != AT_MODE_LOCAL && min1 <= 152)
-				frames = packed16_kernel_exists(kmode_f, layout16_for(tb, hasj, std::min(max1, 152), max2, 4, 8), tb, 4, bits, 8);
+			const int tsf = ovl ? 2 : 4;
+			const int tops[4] = {std::min(max1, 152), std::min(max1, 304), std::min(max1, 608), max1};
+			for (int q = 0; q < 4 && frames; ++q) {
+				const int l1q = ovl ? max1 : tops[q];
+				if (l1q < min1 || (q > 0 && !ovl && tops[q] == tops[q - 1])) continue;
+				const int g = gclass(l1q);
+				frames = packed16_kernel_exists(kmode_f, layout16_for(tb, hasj, l1q, max2, tsf, g, ovl, kmode_f, ovl ? kclass(l1q) : 0), tb, tsf, bits, g);
+				if (ovl) break;
+			}
 		}
-		/* local: the 16-lane groups (their frames mix read lengths freely; on the 8-lane groups, whose lanes carry up to 19
-		 * rows, the same batches ran 15 % slower: 100..150 x 100..150 2.9 against 2.5 ms per 100k pairs) */
-		constexpr int gl = 16;
-		auto kclass = [](int l1) {
-			return gl == 8 ? (l1 <= 40 ? 5 : l1 <= 56 ? 7 : l1 <= 80 ? 10 : l1 <= 104 ? 13 : l1 <= 128 ? 16 : 19)
-			               : (l1 <= 64 ? 4 : l1 <= 80 ? 5 : l1 <= 96 ? 6 : l1 <= 112 ? 7 : l1 <= 160 ? 10 : l1 <= 208 ? 13 : l1 <= 256 ? 16 : 19);
-		};
-		/* global / fit: (group width, rows per lane) of a read length */
-		auto gclass = [](int l1) { return l1 <= 152 ? 8 : 16; };
-		auto kclass2 = [](int l1) { return l1 <= 40 ? 5 : l1 <= 48 ? 6 : l1 <= 56 ? 7 : l1 <= 64 ? 8 : l1 <= 80 ? 10 : l1 <= 104 ? 13 : l1 <= 128 ? 16 : l1 <= 152 ? 19 : l1 <= 160 ? 10 : l1 <= 208 ? 13 : l1 <= 256 ? 16 : 19; };
 		if (frames && mode == AT_MODE_LOCAL) {
-			/* (class descending, l2 descending, index ascending): a counting sort -- the key space is 8 x (max2 + 1) */
-			auto kidx = [&](int l1) {   /* classes in descending order of rows per lane */
+			/* (class descending, l2 descending, index ascending): a counting sort -- the key space is 13 x (max2 + 1) */
+			auto kidx = [&](int l1) {   /* classes in descending order of rows */
+				if (l1 > 304) { const int kc = kclass(l1); return kc == 19 ? 0 : kc == 16 ? 1 : kc == 13 ? 2 : kc == 12 ? 3 : 4; }
 				const int kc = kclass(l1);
-				return gl == 8 ? (kc == 19 ? 0 : kc == 16 ? 1 : kc == 13 ? 2 : kc == 10 ? 3 : kc == 7 ? 4 : 5)
-				               : (kc == 19 ? 0 : kc == 16 ? 1 : kc == 13 ? 2 : kc == 10 ? 3 : kc == 7 ? 4 : kc == 6 ? 5 : kc == 5 ? 6 : 7);
+				return 5 + (kc == 19 ? 0 : kc == 16 ? 1 : kc == 13 ? 2 : kc == 10 ? 3 : kc == 7 ? 4 : kc == 6 ? 5 : kc == 5 ? 6 : 7);
 			};
 			const size_t span = (size_t)max2 + 1;
-			std::vector<int> start(8 * span + 1, 0);
+			std::vector<int> start(13 * span + 1, 0);
 			for (int64_t k = 0; k < npairs; ++k) ++start[(size_t)kidx(len1[k]) * span + (size_t)(max2 - len2[k]) + 1];
 			for (size_t q = 1; q < start.size(); ++q) start[q] += start[q - 1];
 			for (int64_t k = 0; k < npairs; ++k) order[(size_t)start[(size_t)kidx(len1[k]) * span + (size_t)(max2 - len2[k])]++] = (int)k;
 		} else if (frames) {
 			/* (l1 descending, l2 descending, index ascending) by counting sort, then every run of equal l1 padded to whole
-			 * work items (16 alignments on the 8-lane groups, 8 on the 16-lane groups) */
+			 * work items (16 alignments on the 8-lane groups, 8 on the 16-lane groups, 4 on the 32-lane groups, 2 on the 64-lane group) */
 			const size_t span = (size_t)max2 + 1;
 			std::vector<int> start((size_t)(max1 + 1) * span + 1, 0);
 			for (int64_t k = 0; k < npairs; ++k) ++start[(size_t)(max1 - len1[k]) * span + (size_t)(max2 - len2[k]) + 1];
@@ -1069,7 +1171,7 @@ static int align_host(at_handle *h, int mode, int64_t npairs, const uint8_t *seq
 				size_t b1 = b0;
 				const size_t run0 = order.size();
 				while (b1 < sorted.size() && len1[sorted[b1]] == len1[sorted[b0]]) order.push_back(sorted[b1++]);
-				const size_t per = gclass(len1[sorted[b0]]) == 8 ? 16 : 8;
+				const size_t per = (size_t)(2 * (64 / gclass(len1[sorted[b0]])));
 				while ((order.size() - run0) % per) order.push_back(sorted[b1 - 1]);
 				b0 = b1;
 			}
@@ -1086,20 +1188,20 @@ static int align_host(at_handle *h, int mode, int64_t npairs, const uint8_t *seq
 			const int64_t min_bucket = env_ll("AT_RAGGED_MIN_BUCKET", 4096);
 			int nb = 0;
 			for (int64_t b0 = 0; b0 < npairs;) {
-				const int kc = kclass(len1[order[(size_t)b0]]);
+				const int g = gclass(len1[order[(size_t)b0]]), kc = kclass(len1[order[(size_t)b0]]);
 				const int l2first = len2[order[(size_t)b0]];
 				int64_t b1 = b0;
 				int f1 = 0;
 				while (b1 < npairs) {
 					const int x = order[(size_t)b1];
-					if (kclass(len1[x]) != kc) break;
+					if (kclass(len1[x]) != kc || gclass(len1[x]) != g) break;
 					if (b1 - b0 >= min_bucket && (int64_t)len2[x] * 5 < (int64_t)l2first * 4) break;   /* more than 20 % narrower */
 					f1 = std::max(f1, len1[x]);
 					++b1;
 				}
 				rc = align_device(h, mode, b1 - b0, d_words, bits, d_woff1, d_len1, d_woff2, d_len2, f1, l2first, 0, tb ? 1 : 0,
 				                  d_score, d_ei, d_ej, d_st, tb ? d_ops : nullptr, tb ? d_opsoff : nullptr, tb ? d_nops : nullptr, s,
-				                  0, 0, d_order + b0, gl);
+				                  0, 0, d_order + b0, g);
 				if (rc) return rc;
 				b0 = b1;
 				++nb;
@@ -1108,10 +1210,10 @@ static int align_host(at_handle *h, int mode, int64_t npairs, const uint8_t *seq
 		} else if (frames) {
 			int nb = 0;
 			for (size_t b0 = 0; b0 < order.size();) {   /* one launch per (group width, rows per lane) */
-				const int g = gclass(len1[order[b0]]), kc = kclass2(len1[order[b0]]);
+				const int g = gclass(len1[order[b0]]), kc = kclass(len1[order[b0]]);
 				size_t b1 = b0;
 				int f1 = 0, f2 = 0;
-				while (b1 < order.size() && gclass(len1[order[b1]]) == g && kclass2(len1[order[b1]]) == kc) {
+				while (b1 < order.size() && gclass(len1[order[b1]]) == g && kclass(len1[order[b1]]) == kc) {
 					f1 = std::max(f1, len1[order[b1]]); f2 = std::max(f2, len2[order[b1]]);
 					++b1;
 				}
@@ -1130,19 +1232,26 @@ static int align_host(at_handle *h, int mode, int64_t npairs, const uint8_t *seq
 		                  d_score, d_ei, d_ej, d_st, tb ? d_ops : nullptr, tb ? d_opsoff : nullptr, tb ? d_nops : nullptr, s, 0, 0, d_order);
 		if (rc) return rc;
 	}
-	HIP_TRY(h, hipMemcpyAsync(out_score, d_score, (size_t)npairs * 4, hipMemcpyDeviceToHost, s));
-	if (out_end_i) HIP_TRY(h, hipMemcpyAsync(out_end_i, d_ei, (size_t)npairs * 4, hipMemcpyDeviceToHost, s));
-	if (out_end_j) HIP_TRY(h, hipMemcpyAsync(out_end_j, d_ej, (size_t)npairs * 4, hipMemcpyDeviceToHost, s));
-	if (out_state) HIP_TRY(h, hipMemcpyAsync(out_state, d_st, (size_t)npairs * 4, hipMemcpyDeviceToHost, s));
-	/* Only the bytes of each pair's own result travel and are written: the used part of every ops slot (or string
-	 * slot) is packed back to back on the GPU, copied down in one piece and scattered into the caller's slots here.
-	 * Bytes of the caller's buffers between and behind the slots are never touched, whatever order the slots are in. */
-	int rflag = 0;
-	std::vector<int64_t> h_poff;
+	htrace("chunk: sweep queued, pair", pair_base);
+	/* ---- results: the five fixed-size arrays come down in ONE copy into page-locked memory.  Only the bytes of each pair's own
+	 * ---- traceback travel and are written: the used part of every ops slot (or string slot) is packed back to back on the GPU and
+	 * ---- comes down with the same synchronisation -- as many bytes as the previous call's payload suggests, the rest (if this
+	 * ---- batch's tracebacks are longer) behind a second one -- and is scattered into the caller's slots here.  Bytes of the
+	 * ---- caller's buffers between and behind the slots are never touched, whatever order the slots are in. ---- */
+	const size_t res_bytes = 5 * b_len1;
+	const size_t b_str = al((size_t)slots_total + (size_t)npairs + 64);
+	const size_t pk_cap = tb ? (strings ? 2 : 1) * b_str : 0;
+	rc = grow_pinned(h, &h->hp_out, &h->hp_out_bytes, res_bytes + 64 + (tb ? b_pfx : 0) + pk_cap);
+	if (rc) return rc;
+	char *ho = (char *)h->hp_out;
+	int *p_rflag = (int *)(ho + res_bytes);
+	int64_t *h_poff = (int64_t *)(ho + res_bytes + 64);
+	char *h_pk1 = ho + res_bytes + 64 + (tb ? b_pfx : 0), *h_pk2 = h_pk1 + b_str;
+	HIP_TRY(h, hipMemcpyAsync(ho, dout, res_bytes, hipMemcpyDeviceToHost, s));
+	*p_rflag = 0;
 	uint8_t *d_pk1 = nullptr, *d_pk2 = nullptr;
+	size_t spec = 0;                                   /* payload bytes fetched before the total is known */
 	if (tb) {
-		HIP_TRY(h, hipMemcpyAsync(out_nops, d_nops, (size_t)npairs * 4, hipMemcpyDeviceToHost, s));
-		const size_t b_str = al((size_t)slots_total + (size_t)npairs + 64);
 		rc = grow(h, &h->d_str, &h->str_bytes, (strings ? 2 : 1) * b_str + (strings ? b_pfx : 0));
 		if (rc) return rc;
 		d_pk1 = (uint8_t *)h->d_str; d_pk2 = d_pk1 + b_str;
@@ -1159,38 +1268,49 @@ static int align_host(at_handle *h, int mode, int64_t npairs, const uint8_t *seq
 			rc = at_render_batch_device(h, npairs, d_words, bits, d_woff1, d_woff2, d_ei, d_ej, d_ops, d_opsoff, d_nops,
 			                            d_pk1, d_pk2, d_stroff, 1, s);
 			if (rc) return rc;
-			HIP_TRY(h, hipMemcpyAsync(&rflag, h->d_rflag, 4, hipMemcpyDeviceToHost, s));
+			HIP_TRY(h, hipMemcpyAsync(p_rflag, h->d_rflag, 4, hipMemcpyDeviceToHost, s));
 		}
-		h_poff.resize((size_t)npairs + 1);
-		HIP_TRY(h, hipMemcpyAsync(h_poff.data(), d_poff, (size_t)(npairs + 1) * 8, hipMemcpyDeviceToHost, s));
+		HIP_TRY(h, hipMemcpyAsync(h_poff, d_poff, (size_t)(npairs + 1) * 8, hipMemcpyDeviceToHost, s));
+		spec = std::min<size_t>((size_t)slots_total + (strings ? (size_t)npairs : 0),
+		                        (size_t)((double)h->last_payload_per_pair * 1.25 * (double)npairs) + 65536);
+		HIP_TRY(h, hipMemcpyAsync(h_pk1, d_pk1, spec, hipMemcpyDeviceToHost, s));
+		if (strings) HIP_TRY(h, hipMemcpyAsync(h_pk2, d_pk2, spec, hipMemcpyDeviceToHost, s));
 	}
 	HIP_TRY(h, hipStreamSynchronize(s));
+	htrace("chunk: results down, pair", pair_base);
+	const int32_t *r_score = (const int32_t *)ho, *r_nops = (const int32_t *)(ho + 4 * b_len1);
 	for (int64_t k = 0; k < npairs; ++k) {
-		if (out_score[k] == INT32_MIN || (tb && out_nops[k] < 0))
+		if (r_score[k] == INT32_MIN || (tb && r_nops[k] < 0))
 			return fail(h, AT_ERR_DOMAIN, "pair %lld: input outside the domain on which the reference is defined", (long long)(pair_base + k));
 	}
+	memcpy(out_score, ho, (size_t)npairs * 4);
+	if (out_end_i) memcpy(out_end_i, ho + b_len1, (size_t)npairs * 4);
+	if (out_end_j) memcpy(out_end_j, ho + 2 * b_len1, (size_t)npairs * 4);
+	if (out_state) memcpy(out_state, ho + 3 * b_len1, (size_t)npairs * 4);
 	if (tb) {
+		memcpy(out_nops, r_nops, (size_t)npairs * 4);
 		const int64_t total = h_poff[(size_t)npairs];
 		if (total < 0 || total > slots_total) return fail(h, AT_ERR_DOMAIN, "traceback lengths inconsistent with the slots");
+		const size_t have = (size_t)total + (strings ? (size_t)npairs : 0);
+		h->last_payload_per_pair = (double)have / (double)npairs;
+		if (have > spec) {       /* longer tracebacks than the last batch's: the rest of the payload */
+			HIP_TRY(h, hipMemcpyAsync(h_pk1 + spec, d_pk1 + spec, have - spec, hipMemcpyDeviceToHost, s));
+			if (strings) HIP_TRY(h, hipMemcpyAsync(h_pk2 + spec, d_pk2 + spec, have - spec, hipMemcpyDeviceToHost, s));
+			HIP_TRY(h, hipStreamSynchronize(s));
+		}
 		if (!strings) {
-			std::vector<uint8_t> pk((size_t)total + 1);
-			if (total) HIP_TRY(h, hipMemcpyAsync(pk.data(), d_pk1, (size_t)total, hipMemcpyDeviceToHost, s));
-			HIP_TRY(h, hipStreamSynchronize(s));
 			for (int64_t k = 0; k < npairs; ++k)
-				if (out_nops[k] > 0) memcpy(out_ops + ops_off[k], pk.data() + h_poff[(size_t)k], (size_t)out_nops[k]);
+				if (r_nops[k] > 0) memcpy(out_ops + ops_off[k], h_pk1 + h_poff[(size_t)k], (size_t)r_nops[k]);
 		} else {
-			std::vector<char> p1((size_t)(total + npairs) + 1), p2((size_t)(total + npairs) + 1);
-			HIP_TRY(h, hipMemcpyAsync(p1.data(), d_pk1, (size_t)(total + npairs), hipMemcpyDeviceToHost, s));
-			HIP_TRY(h, hipMemcpyAsync(p2.data(), d_pk2, (size_t)(total + npairs), hipMemcpyDeviceToHost, s));
-			HIP_TRY(h, hipStreamSynchronize(s));
 			for (int64_t k = 0; k < npairs; ++k) {
-				const size_t src = (size_t)(h_poff[(size_t)k] + k), n = (size_t)out_nops[k] + 1;   /* with the NUL */
-				memcpy(out_r1 + ops_off[k], p1.data() + src, n);
-				memcpy(out_r2 + ops_off[k], p2.data() + src, n);
+				const size_t src = (size_t)(h_poff[(size_t)k] + k), nb = (size_t)r_nops[k] + 1;   /* with the NUL */
+				memcpy(out_r1 + ops_off[k], h_pk1 + src, nb);
+				memcpy(out_r2 + ops_off[k], h_pk2 + src, nb);
 			}
 		}
 	}
-	if (rflag) return fail(h, AT_ERR_DOMAIN, "traceback inconsistent with its sequences");
+	if (*p_rflag) return fail(h, AT_ERR_DOMAIN, "traceback inconsistent with its sequences");
+	htrace("chunk: done, pair", pair_base);
 	return AT_OK;
 }
 
@@ -1205,11 +1325,12 @@ static int align_host_mt(at_handle *h, int mode, int64_t npairs, const uint8_t *
 {
 	/* uniform batches: six chunks (100k pairs of C2: 3.37 ms in one piece, 2.49 in 3 chunks, 2.28 in 6); ragged ones, whose chunks are
 	 * sorted into frames one by one: three (fit -s 100..150 x 400..500: 785 GCUPS in 3 chunks, 693 in 6 -- smaller frames) */
+	htrace("batch: enter, pairs", npairs);
 	bool same = len1 && len2;
 	for (int64_t k = 1; same && k < npairs; ++k) same = len1[k] == len1[0] && len2[k] == len2[0];
-	const long long want = env_ll("AT_HOST_CHUNKS", same ? 6 : 3);
-	const long long min_pairs = env_ll("AT_HOST_CHUNK_MIN", 16384);
-	int nchunks = (int)std::max<long long>(1, std::min<long long>(want, 8));
+	const long long want = env_ll("AT_HOST_CHUNKS", same ? 8 : 3);
+	const long long min_pairs = env_ll("AT_HOST_CHUNK_MIN", same ? 8192 : 16384);
+	int nchunks = (int)std::max<long long>(1, std::min<long long>(want, 12));
 	if (!h || npairs < 2 * min_pairs || !seq_blob || !off1 || !len1 || !off2 || !len2 || !out_score) nchunks = 1;
 	else nchunks = (int)std::min<long long>(nchunks, npairs / min_pairs);
 	if (nchunks <= 1)
@@ -1233,6 +1354,15 @@ static int align_host_mt(at_handle *h, int mode, int64_t npairs, const uint8_t *
 	std::vector<int> rcs((size_t)nchunks, AT_OK);
 	std::vector<std::thread> th;
 	const int64_t per = ((npairs + nchunks - 1) / nchunks + 7) & ~(int64_t)7;
+	UploadGate gate;
+	const bool ordered = env_ll("AT_HOST_ORDERED_UPLOADS", 1) != 0;
+	if (ordered) {
+		HIP_TRY(h, hipSetDevice(h->device));
+		for (int c = 0; c < nchunks; ++c) {
+			if (!h->ev_upload[c]) HIP_TRY(h, hipEventCreateWithFlags(&h->ev_upload[c], hipEventDisableTiming));
+			gate.done[c] = h->ev_upload[c];
+		}
+	}
 	auto run = [&](int c) {
 		const int64_t lo = std::min<int64_t>(npairs, c * per), n = std::min<int64_t>(npairs, lo + per) - lo;
 		at_handle *hh = c == 0 ? h : h->kids[(size_t)c - 1];
@@ -1240,7 +1370,7 @@ static int align_host_mt(at_handle *h, int mode, int64_t npairs, const uint8_t *
 		rcs[(size_t)c] = align_host(hh, mode, n, seq_blob, off1 + lo, len1 + lo, off2 + lo, len2 + lo, want_traceback,
 		                            out_score + lo, out_end_i ? out_end_i + lo : nullptr, out_end_j ? out_end_j + lo : nullptr,
 		                            out_state ? out_state + lo : nullptr, out_ops, ops_off ? ops_off + lo : nullptr,
-		                            out_nops ? out_nops + lo : nullptr, out_r1, out_r2, lo);
+		                            out_nops ? out_nops + lo : nullptr, out_r1, out_r2, lo, ordered ? &gate : nullptr, c);
 	};
 	for (int c = 1; c < nchunks; ++c) th.emplace_back(run, c);
 	run(0);

@@ -12,7 +12,9 @@
 	at_sweep16_fn at_pick16_rag8c_b##b(int kmode, int k, int store, bool tb);      \
 	at_sweep16_fn at_pick16_rag8d_b##b(int kmode, int k, int store, bool tb);      \
 	at_sweep16_fn at_pick16_rag16_b##b(int kmode, int k, int store, bool tb);      \
-	at_sweep16_fn at_pick16_rag16b_b##b(int kmode, int k, int store, bool tb);
+	at_sweep16_fn at_pick16_rag16b_b##b(int kmode, int k, int store, bool tb);     \
+	at_sweep16_fn at_pick16_rag32_b##b(int kmode, int k, int store, bool tb);      \
+	at_sweep16_fn at_pick16_ragovl_b##b(int k, int store);
 AT_DECL(2)
 AT_DECL(8)
 #undef AT_DECL
@@ -35,6 +37,8 @@ at_sweep16_fn at_pick16_rag(int kmode, int g, int k, int store, bool tb, int bit
 		if (bits == 8) return k >= 19 ? at_pick16_rag8c_b8(kmode, k, store, tb) : k >= 13 ? at_pick16_rag8b_b8(kmode, k, store, tb) : at_pick16_rag8a_b8(kmode, k, store, tb);
 		return k >= 19 ? at_pick16_rag8c_b2(kmode, k, store, tb) : k >= 13 ? at_pick16_rag8b_b2(kmode, k, store, tb) : at_pick16_rag8a_b2(kmode, k, store, tb);
 	}
+	if (kmode == at::K_OVERLAP) return g != 64 || !tb ? nullptr : bits == 8 ? at_pick16_ragovl_b8(k, store) : at_pick16_ragovl_b2(k, store);
+	if (g == 32) return bits == 8 ? at_pick16_rag32_b8(kmode, k, store, tb) : at_pick16_rag32_b2(kmode, k, store, tb);
 	if (g != 16) return nullptr;
 	if (k >= 16) return bits == 8 ? at_pick16_rag16b_b8(kmode, k, store, tb) : at_pick16_rag16b_b2(kmode, k, store, tb);   /* reads of 209..304 bases */
 	if (kmode == at::K_LOCAL) return bits == 8 ? at_pick16_rag_impl_b8(k, store, tb) : at_pick16_rag_impl_b2(k, store, tb);

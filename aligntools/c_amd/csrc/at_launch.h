@@ -4,7 +4,7 @@
 #include "at_sweep16.hip.h"
 
 typedef void (*at_sweep_fn)(const at::SweepArgs);
-typedef void (*at_sweep16_fn)(const at::Sweep16Args);
+typedef void (*at_sweep16_fn)(const at::Sweep16Args, const at::Sweep16Args);   /* (batch, its sliver on 64-lane items) */
 namespace at { struct MyersArgs; }
 typedef void (*at_myers_fn)(const at::MyersArgs);
 at_myers_fn at_pick_myers(int w, int g);   /* w in {1,2,4,8} 32-bit words per lane, g in {32, 8} lanes per alignment */

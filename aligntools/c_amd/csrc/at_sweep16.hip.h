@@ -38,7 +38,6 @@
 #ifndef AT_WALK_AHEAD
 #define AT_WALK_AHEAD 4   /* fit walks: pointer words loaded ahead along the current run (C4: 2 -> 1.96, 4 -> 2.07, 8 -> 2.01 TCUPS) */
 #endif
-#ifndef AT_WALK_PRIO
 #ifndef AT_DIAG_NO_WALK
 #define AT_DIAG_NO_WALK 0   /* 1: throw-away build without the traceback walks (what do they cost?); every pair reports 0 ops */
 #endif
@@ -52,8 +51,16 @@
 #define AT_LOCAL_WALK_AHEAD 1    /* and local ones, although those of unrelated reads are a dozen ops long (C2 on the 8-lane groups: 2 966 ->
                                   * 3 042 GCUPS with launches in flight, 2 266 -> 2 447 alone; on 16-lane groups round 1 had measured -4 %) */
 #endif
+#ifndef AT_WALK_PRIO
 #define AT_WALK_PRIO 2    /* s_setprio of a wave while it walks: the walk is a chain of dependent loads with a few instructions in
                           * between, which should not queue behind the other waves' sweeps (C3 +2.5 %, C4 +1 %; 0 = off) */
+#endif
+#ifndef AT_JPLANE
+#define AT_JPLANE 1       /* fit -s, scores x16: 4-bit pointer cells + a bit plane for the jump state's pointers (5 bits per cell and
+                          * alignment instead of 8; 0 = the round-2 byte cells, for A/B runs) */
+#endif
+#ifndef AT_OVL_BITS
+#define AT_OVL_BITS 2     /* packed overlap: bits per pointer cell (the walk reads 2; 4 = the round-2 nibble cells, for A/B runs) */
 #endif
 
 namespace at {
@@ -189,7 +196,9 @@ AT_DEV uint32_t grp_up1(uint32_t old, uint32_t src)
 template <int PB>
 AT_DEV int cell_shift(int sw)
 {
-	return PB == 8 ? 8 * sw : 8 * (sw & 1) + 4 * (sw >> 1);
+	/* 8-bit cells: two steps per half.  4-bit cells: nibbles [step 3 | step 1 | step 2 | step 0].  2-bit cells (overlap): two such
+	 * nibble words on top of each other, steps 0..3 in bits [1:0] of the nibbles, steps 4..7 in bits [3:2] */
+	return PB == 8 ? 8 * sw : PB == 4 ? 8 * (sw & 1) + 4 * (sw >> 1) : 8 * (sw & 1) + 4 * ((sw >> 1) & 1) + 2 * (sw >> 2);
 }
 
 template <bool LDS, int K>
@@ -202,11 +211,13 @@ AT_DEV int pidx(int wr, int r, int lane, int NL)
 	else return r < KF ? __mul24(wr, NL * K) + __mul24(r & ~3, NL) + lane * 4 + (r & 3) : __mul24(wr, NL * K) + KF * NL + lane * KR + (r - KF);
 }
 
+/* The work items [wbase, wbase + items of `a`) of one launch, pulled from the launch's work counter: `wnext` is the item this wave
+ * holds when it gets here (its block index, or what an earlier call left over); returns the first item beyond the range. */
 template <int MODE, int G, int K, int TS, bool SMALL, bool PTRLDS, bool TB, bool RAG = false, int BITS = 2>
-__global__ __launch_bounds__(64, AT_WAVES16(G, K)) void at_sweep16(const Sweep16Args a)
+AT_DEV long long sweep16_items(const Sweep16Args &a, long long wnext, const long long wbase)
 {
 	static_assert(BITS == 2 || BITS == 8, "sequence words: 16 two-bit codes or 4 bytes");
-	static_assert(!RAG || G <= 16, "ragged frames: one strip");
+	static_assert(!RAG || G <= 32 || MODE == K_OVERLAP, "ragged frames: one strip (the host sizes the frame for it)");
 	static_assert(MODE == K_GLOBAL || MODE == K_LOCAL || MODE == K_FIT || MODE == K_FITJ || MODE == K_OVERLAP, "packed path: the affine modes, overlap");
 	/* overlap (align_overlap, alignment.h:926-964): ONE state with a linear gap, M = max5(M(i,j-1) + o, M(i-1,j-1) + s,
 	 * M(i-1,j) + o), first wins in that order -> tags LEFT 3 / DIAGONAL 2 / RIGHT 1 on the three candidates (the diagonal
@@ -214,7 +225,7 @@ __global__ __launch_bounds__(64, AT_WAVES16(G, K)) void at_sweep16(const Sweep16
 	 * column (left neighbour, and diagonal input of the row below); 9.25 instructions per row-step with pointers.  Only
 	 * built with pointers: without them the int32 kernel's three instructions per cell (SDWA add, v_max3_i32, add) win. */
 	constexpr bool OVL = MODE == K_OVERLAP;
-	static_assert(!OVL || (TB && TS == 2 && !RAG), "packed overlap: scores x4 with 2-bit tags, tracebacks, uniform batches");
+	static_assert(!OVL || (TB && TS == 2), "packed overlap: scores x4 with 2-bit tags, tracebacks");
 	constexpr bool HASJ = MODE == K_FITJ;
 	constexpr bool ISFIT = MODE == K_FIT || MODE == K_FITJ;
 	static_assert(TS == 4 || TS == 2, "scores x16 or x4");
@@ -227,7 +238,13 @@ __global__ __launch_bounds__(64, AT_WAVES16(G, K)) void at_sweep16(const Sweep16
 	 * per row-step less, and tag the three end-cell candidates of global only to report the start state. */
 	constexpr int OTGL = TS == 4 ? 15 : 3, OTGM = TS == 4 ? 10 : 2, OTGU = 1;
 	constexpr int TGL = TB ? OTGL : 0, TGM = TB ? OTGM : 0, TGU = TB ? OTGU : 0;
-	constexpr int PB = HASJ ? 8 : 4;          /* pointer bits per cell and alignment */
+	/* Jump state with scores x16: the cell keeps the 4 bits of the other modes and the jump state's own pointer (did J open from
+	 * M here?) goes to a BIT PLANE beside the cells -- one word per 4 rows x 4 steps and half -- 5 bits per cell instead of the 8 of a
+	 * byte cell.  (Scores x4 carry score bits in the low nibble of J: they keep the byte cells.) */
+	constexpr bool JPL = HASJ && TB && TS == 4 && AT_JPLANE;
+	constexpr int KG = (K + 3) / 4;           /* groups of 4 rows of the plane */
+	constexpr int PB = OVL ? AT_OVL_BITS : (HASJ && !JPL) ? 8 : 4;   /* pointer bits per cell and alignment */
+	static_assert(!OVL || G == 64, "packed overlap: one 64-lane group");
 	constexpr int SPW = 16 / PB;              /* steps per pointer word (each half holds its own alignment) */
 	static_assert(G == 64 || G == 32 || G == 16 || G == 8 || G == 4, "group width");
 	constexpr int NG = 64 / G;                /* groups per wavefront, 2 alignments each */
@@ -258,6 +275,8 @@ __global__ __launch_bounds__(64, AT_WAVES16(G, K)) void at_sweep16(const Sweep16
 	uint32_t cClean = (uint32_t)(0xffff & ~TMASK) * 0x00010001u, cTagM = (uint32_t)TGM * 0x00010001u;
 	uint32_t cTagL = (uint32_t)TGL * 0x00010001u, cTagU = (uint32_t)TGU * 0x00010001u;
 	uint32_t cM3 = 0x00030003u, cM7 = 0x00070007u, cNib = 0x000f000fu, cF0 = 0x00f000f0u, cF000 = 0xf000f000u;
+	uint32_t c8888 = 0x88888888u, c3333 = 0x33333333u;
+	asm volatile("" : "+v"(c8888), "+v"(c3333));
 	/* jump state: J(i,j) = max(M(i,j-1) + g, J(i,j-1)) where the column may open, else J(i,j-1) (alignment.h:658-666);
 	 * the left state holds M + o, so the opening candidate is (M + o) + (g - o), or -inf where opening is barred */
 	uint32_t gmo2 = pk2(a.g16 - a.o16), neg2 = 0x80008000u;
@@ -269,14 +288,13 @@ __global__ __launch_bounds__(64, AT_WAVES16(G, K)) void at_sweep16(const Sweep16
 	const int nstrips = (l1 + RS - 1) / RS;   /* host guarantees 1 when G < 64 */
 	const int tbk_frame = (l2 + G - 1 + BLK - 1) / BLK;
 	const int wps = tbk_frame * RPB * K;      /* pointer word rows per strip (the layout of the slot: always the frame's) */
+	const int wpj = tbk_frame * (BLK / 4) * KG;   /* jump plane: word rows per strip, behind the cells of all strips */
+	const int jpl_base0 = a.off_ptr + __mul24(nstrips * wps, NL);
 	const long long nwork = (a.npairs + 2 * NG - 1) / (2 * NG);
 	const int refoff = grp * 2 * a.off_refb;  /* my group's two s2 byte arrays */
 
-	if (a.only_if && __builtin_amdgcn_readfirstlane(*a.only_if) != a.only_val) return;
-
-	long long wnext = blockIdx.x;
-	while (wnext < nwork) {
-		const long long wk = wnext;
+	while (wnext - wbase < nwork) {
+		const long long wk = wnext - wbase;
 		wnext = next_work(a.queue, lane);   /* consumed at the end of this work item: latency hidden */
 		const long long last = a.npairs - 1;
 		long long pA = (wk * NG + grp) * 2 < a.npairs ? (wk * NG + grp) * 2 : last;
@@ -369,6 +387,7 @@ __global__ __launch_bounds__(64, AT_WAVES16(G, K)) void at_sweep16(const Sweep16
 		/* Xl: X' of my rows at the previous column (the diagonal input of the row below).  Two copies used in turn
 		 * (step parity), so that the old value can be read while the new one is written without register moves. */
 		uint32_t Mo_l[K], U_l[K], Xl[2][K], L_l[K], J_l[K];
+		uint32_t Lrow = 0;                             /* fit: L of row l1 at the previous column (what the end-cell scan reads) */
 
 		for (int s = 0; s < nstrips; ++s) {
 			const int base = s * RS;
@@ -377,6 +396,14 @@ __global__ __launch_bounds__(64, AT_WAVES16(G, K)) void at_sweep16(const Sweep16
 			const bool laststrip = s == nstrips - 1;
 			const bool wb = G == 64 && !laststrip;
 			uint32_t qsel[K], acc[K], keymask[K];
+			uint32_t accH[OVL && PB == 2 ? K : 1];   /* overlap, 2-bit cells: the nibble word of steps 4..7 until it joins that of steps 0..3 */
+			uint32_t jA[JPL ? KG : 1], jB[JPL ? KG : 1];   /* jump plane: per group of 4 rows, the J nibbles of the block's steps on their way into one word */
+			(void)accH; (void)jA; (void)jB;
+			if constexpr (JPL) {
+#pragma unroll
+				for (int g = 0; g < KG; ++g) { jA[g] = 0; jB[g] = 0; }   /* (their words are OR-ed together: no stray bits from before the lane's first step) */
+			}
+			const int jpl_base = jpl_base0 + __mul24(s * wpj, NL);
 #pragma unroll
 			for (int r = 0; r < K; ++r) {
 				const int qi = imin(i0 + r, l1A - 1), qj = imin(i0 + r, l1B - 1);
@@ -396,6 +423,7 @@ __global__ __launch_bounds__(64, AT_WAVES16(G, K)) void at_sweep16(const Sweep16
 				Mo_l[r] = pk2(sat16((M | TGM) + o16));
 				U_l[r] = pk2(U | TGU);
 				L_l[r] = pk2(L | TGL);
+				if constexpr (ISFIT) Lrow = L_l[r];       /* (fit: the same border value in every row) */
 				J_l[r] = neg2;                    /* J is -inf on both borders (:616, :622) */
 				Xl[0][r] = pk2(imax3(L | TGL, M | TGM, U | TGU));
 				if constexpr (OVL) Xl[0][r] = 0;  /* M(i,0) = 0 */
@@ -470,7 +498,12 @@ __global__ __launch_bounds__(64, AT_WAVES16(G, K)) void at_sweep16(const Sweep16
 							/* end-cell scan of row l1, columns 0..l2-1 (:951-959), one column behind the sweep */
 							if (laststrip) {
 								const uint32_t jpk = pk2(jm1);
-								const uint32_t vM = pick<K>(Xl[k & 1], rl);
+								uint32_t vM = pick<K>(Xl[k & 1], rl);
+								if constexpr (RAG) {
+									/* an alignment's scan ends at its own column l2 - 1 */
+									const uint32_t cm = (((uint32_t)((jm1 - l2A) >> 31)) & 0xffffu) | (((uint32_t)((jm1 - l2B) >> 31)) << 16);
+									vM = vbfi(cm, vM, neg2);
+								}
 								uint32_t dM = psub(bestM, vM);
 								asm("" : "+v"(dM));
 								bestMj = vbfi(pneg(dM), jpk, bestMj); bestM = pmax(bestM, vM);
@@ -484,7 +517,7 @@ __global__ __launch_bounds__(64, AT_WAVES16(G, K)) void at_sweep16(const Sweep16
 							if (laststrip) {
 								const uint32_t jpk = pk2(jm1);
 								uint32_t vM = psub(pick<K>(Mo_l, rl), o2);
-								uint32_t vL = pick<K>(L_l, rl);
+								uint32_t vL = Lrow;
 								if constexpr (RAG) {
 									/* an alignment's scan ends at its own column l2 - 1 */
 									const uint32_t cm = (((uint32_t)((jm1 - l2A) >> 31)) & 0xffffu) | (((uint32_t)((jm1 - l2B) >> 31)) << 16);
@@ -508,6 +541,8 @@ __global__ __launch_bounds__(64, AT_WAVES16(G, K)) void at_sweep16(const Sweep16
 							if (lg == lastlane) capmask = (jm1 + 1 == l2A ? 0xffffu : 0u) | (jm1 + 1 == l2B ? 0xffff0000u : 0u);
 						}
 						uint32_t upv = Aup;                         /* overlap: M of the row above in this column */
+						uint32_t jn = 0;                            /* jump plane: the J nibbles of the current group of 4 rows */
+						(void)jn;
 #pragma unroll
 						for (int r = 0; r < K; ++r) {
 							/* x = s2 byte ^ query byte (0 = match): selector {xB+4, xB, xA+4, xA} -> the two 16-bit scores */
@@ -524,10 +559,24 @@ __global__ __launch_bounds__(64, AT_WAVES16(G, K)) void at_sweep16(const Sweep16
 								const uint32_t x = pmax(pmax(padd(left, oL2), padd(diag, S)), padd(upv, oR2));
 								const uint32_t Mcl = x & cClean;
 								constexpr int sw = k % SPW;         /* pointer word: see the affine modes below */
-								if constexpr (sw == 0) acc[r] = x;
-								else if constexpr (sw == 1) acc[r] = __builtin_amdgcn_perm(x, acc[r], 0x06020400u);
-								else if constexpr (sw == 2) acc[r] = vbfi(cF0, pshln<4>(x), acc[r]);
-								else acc[r] = vbfi(cF000, pshln<12>(x), acc[r]);
+								if constexpr (PB == 4) {
+									if constexpr (sw == 0) acc[r] = x;
+									else if constexpr (sw == 1) acc[r] = __builtin_amdgcn_perm(x, acc[r], 0x06020400u);
+									else if constexpr (sw == 2) acc[r] = vbfi(cF0, pshln<4>(x), acc[r]);
+									else acc[r] = vbfi(cF000, pshln<12>(x), acc[r]);
+								} else {
+									/* 2-bit cells: the walk reads the tag alone, so the nibble words of steps 0..3 and 4..7 share one word --
+									 * bits [1:0] of every nibble from the first, [3:2] from the second (two instructions per 8 steps more,
+									 * half the pointer bytes) */
+									if constexpr (sw == 0) acc[r] = x;
+									else if constexpr (sw == 1) acc[r] = __builtin_amdgcn_perm(x, acc[r], 0x06020400u);
+									else if constexpr (sw == 2) acc[r] = vbfi(cF0, pshln<4>(x), acc[r]);
+									else if constexpr (sw == 3) acc[r] = vbfi(cF000, pshln<12>(x), acc[r]);
+									else if constexpr (sw == 4) accH[r] = x;
+									else if constexpr (sw == 5) accH[r] = __builtin_amdgcn_perm(x, accH[r], 0x06020400u);
+									else if constexpr (sw == 6) accH[r] = vbfi(cF0, pshln<4>(x), accH[r]);
+									else accH[r] = vbfi(cF000, pshln<12>(x), accH[r]);   /* (the two words join where they are stored: a lane may sit out step 7) */
+								}
 								diag = left;
 								upv = Mcl;
 								up = Mcl;
@@ -565,7 +614,29 @@ __global__ __launch_bounds__(64, AT_WAVES16(G, K)) void at_sweep16(const Sweep16
 									/* 2-bit tags: bit 0 of the L winner (3 ext / 2 open) and of the U winner (1 ext / 2 open) */
 									c = vbfi(cM7, vbfi(cM3, Mraw, pshln<2>(lraw)), pshln<3>(Uraw));
 								}
-								if constexpr (HASJ) c = vbfi(cNib, c, pshln<TS == 4 ? 1 : 3>(Jraw));   /* J winner's tag: M's (open) or 0 */
+								if constexpr (HASJ && !JPL) c = vbfi(cNib, c, pshln<TS == 4 ? 1 : 3>(Jraw));   /* J winner's tag: M's (open) or 0 */
+								if constexpr (JPL) {
+									/* The low nibble of the J winner is M's tag 1010 (J opened here) or 0000 (extended, or -inf): the nibbles of 4
+									 * rows are gathered like the steps of a cell word -- [row 3 | row 1 | row 2 | row 0] -- and because bits 2 and 0
+									 * of every nibble are 0, the gathered words of the block's 4 steps interleave into ONE word: bit 1 step 0,
+									 * bit 3 step 1, bit 0 step 2, bit 2 step 3 of each row's nibble (1.5 instructions per row-step). */
+									const int q = r & 3, gq = r >> 2;
+									if (q == 0) jn = Jraw;
+									else if (q == 1) jn = __builtin_amdgcn_perm(Jraw, jn, 0x06020400u);
+									else if (q == 2) jn = vbfi(cF0, pshln<4>(Jraw), jn);
+									else jn = vbfi(cF000, pshln<12>(Jraw), jn);
+									if (q == 3 || r == K - 1) {
+										/* (a last group of fewer than 4 rows: what the gather left in the other nibbles must not leak into the interleave) */
+										if (q == 0) jn &= 0x000f000fu; else if (q == 1) jn &= 0x0f0f0f0fu; else if (q == 2) jn &= 0x0fff0fffu;
+										constexpr int sj = k & 3;
+										if constexpr (sj == 0) jA[gq] = jn;
+										else if constexpr (sj == 1) jA[gq] = vbfi(c8888, jn, jA[gq]);
+										else if constexpr (sj == 2) jB[gq] = jn;
+										else jB[gq] = vbfi(c8888, jn, jB[gq]);   /* (jA: steps 1 | 0, jB: steps 3 | 2 in bits 3 | 1 of every nibble; they interleave
+										                                          * where they are stored -- a lane may sit out the block's last step.  Stale
+										                                          * nibbles of a step the lane sat out only ever reach that step's own bits.) */
+									}
+								}
 								/* assembling the word of SPW steps costs 1.25 instructions per step (4-bit cells) or 0.5 (8-bit cells)
 								 * instead of a mask and a shift-or per step: bytes are gathered with v_perm, which does not care what
 								 * the unused bits of a byte hold; half h of the word: 8-bit cells [step 1 | step 0], 4-bit cells
@@ -586,7 +657,8 @@ __global__ __launch_bounds__(64, AT_WAVES16(G, K)) void at_sweep16(const Sweep16
 							lraw = Ld;
 							up = Xo;
 							Mo_l[r] = Mo; U_l[r] = Uc;
-							if constexpr (MODE != K_LOCAL) L_l[r] = Lc;
+							if constexpr (MODE == K_GLOBAL) L_l[r] = Lc;
+							if constexpr (ISFIT) Lrow = r == rl ? Lc : Lrow;   /* (one register instead of K: the scan reads row l1 only) */
 						}
 						if constexpr (MODE == K_LOCAL) {
 							if constexpr (RAG) {
@@ -610,6 +682,12 @@ __global__ __launch_bounds__(64, AT_WAVES16(G, K)) void at_sweep16(const Sweep16
 					}
 					Ad = Aup;
 					if constexpr (TB) {
+						if constexpr (OVL && PB == 2) {
+							if constexpr ((k + 1) % SPW == 0) {
+#pragma unroll
+								for (int r = 0; r < K; ++r) acc[r] = vbfi(c3333, acc[r], accH[r] << 2);
+							}
+						}
 						if ((k + 1) % SPW == 0 && lane < NL) {
 							if constexpr (PTRLDS) {
 #pragma unroll
@@ -628,6 +706,32 @@ __global__ __launch_bounds__(64, AT_WAVES16(G, K)) void at_sweep16(const Sweep16
 									pm.st2(ptr_base + pidx<false, K>(wr, R4, lane, NL), acc[R4], acc[R4 + 1]);
 								} else if constexpr (K - R4 == 1) {
 									pm.st(ptr_base + pidx<false, K>(wr, R4, lane, NL), acc[R4]);
+								}
+							}
+						}
+						if constexpr (JPL) {
+							if ((k & 3) == 3 && lane < NL) {
+								const int wr = blk * (BLK / 4) + k / 4;
+								uint32_t jO[KG];
+#pragma unroll
+								for (int g = 0; g < KG; ++g) jO[g] = jA[g] | (jB[g] >> 1);
+								if constexpr (PTRLDS) {
+#pragma unroll
+									for (int g = 0; g < KG; ++g) pm.st(jpl_base + pidx<true, KG>(wr, g, lane, NL), jO[g]);
+								} else {
+#pragma unroll
+									for (int g = 0; g + 3 < KG; g += 4)
+										pm.st4(jpl_base + pidx<false, KG>(wr, g, lane, NL), jO[g], jO[g + 1], jO[g + 2], jO[g + 3]);
+									constexpr int G4 = KG / 4 * 4;
+									if constexpr (KG - G4 == 3) {
+										pm.st(jpl_base + pidx<false, KG>(wr, G4, lane, NL), jO[G4]);
+										pm.st(jpl_base + pidx<false, KG>(wr, G4 + 1, lane, NL), jO[G4 + 1]);
+										pm.st(jpl_base + pidx<false, KG>(wr, G4 + 2, lane, NL), jO[G4 + 2]);
+									} else if constexpr (KG - G4 == 2) {
+										pm.st2(jpl_base + pidx<false, KG>(wr, G4, lane, NL), jO[G4], jO[G4 + 1]);
+									} else if constexpr (KG - G4 == 1) {
+										pm.st(jpl_base + pidx<false, KG>(wr, G4, lane, NL), jO[G4]);
+									}
 								}
 							}
 						}
@@ -776,17 +880,63 @@ __global__ __launch_bounds__(64, AT_WAVES16(G, K)) void at_sweep16(const Sweep16
 						while (ci > 0 && (ISFIT || cj > 0)) {     /* (global, trace_back_gla :384-397: until either index is 0, then the padding loops) */
 							if (MODE == K_LOCAL && st == 0) break;              /* HOME :788-791 (the cell that pointed home has been emitted) */
 							if (cj <= 0 || cnt >= l1 + l2) { ok = false; break; }   /* (a walk never has more ops than its slot holds) */
+							/* jump state with the bit plane (:579-583): the walk runs left along its row until the column where J opened from M;
+							 * the plane holds 4 columns of the row per word, so the same four loads -- issued together with those of the walks in
+							 * the other states: one round trip to HBM for all 2 .. 16 walks of the wavefront -- cover up to 16 columns */
+							const bool inJ = JPL && st == 0;
 							const int di = st >= 2 ? 1 : 0, dj = st == 3 ? 0 : 1;
+							/* the cell (ci, cj): strip, lane in group, row in lane -- the cells ahead along the run differ from it by at most
+							 * AHEAD - 1 rows, so one division serves all of them */
+							const int ss0 = G == 64 ? (ci - 1) / RS : 0, li0 = G == 64 ? (ci - 1) % RS : ci - 1;
+							const int ln0 = li0 / K, r0 = li0 % K;
 							uint32_t w[AHEAD];
 							int sh[AHEAD];
 #pragma unroll
 							for (int q = 0; q < AHEAD; ++q) {
-								const int qi = imax(ci - q * di, 1), qj = imax(cj - q * dj, 1);   /* (clamped cells are never consumed) */
-								const int ss = G == 64 ? (qi - 1) / RS : 0, li = G == 64 ? (qi - 1) % RS : qi - 1;
-								const int ln = li / K, r = li % K;
-								const int t = (qj - 1) + ln;
+								int ss = ss0, ln = ln0, r = r0;
+								if (q * di > 0 && q * di < ci) {                 /* (cells beyond row 1 are never consumed: any address will do) */
+									if constexpr (K >= AHEAD) {
+										r = r0 - q * di;
+										if (r < 0) { r += K; --ln; }
+										if (G == 64 && ln < 0) { ln += 64; --ss; }
+									} else {
+										const int qi = ci - q * di;
+										ss = G == 64 ? (qi - 1) / RS : 0;
+										const int li = G == 64 ? (qi - 1) % RS : qi - 1;
+										ln = li / K; r = li % K;
+									}
+								}
+								const int t = (imax(cj - q * dj, 1) - 1) + ln;
+								int idx = a.off_ptr + (G == 64 ? __mul24(ss, wps * NL) : 0) + pidx<PTRLDS, K>(t / SPW, r, glane + ln, NL);
 								sh[q] = 16 * h + cell_shift<PB>(t % SPW);
-								w[q] = pm.ld(a.off_ptr + (G == 64 ? __mul24(ss, wps * NL) : 0) + pidx<PTRLDS, K>(t / SPW, r, glane + ln, NL));
+								if constexpr (JPL) {
+									/* (in the jump state every q has the walk's own row and step: word q is the block q to the left) */
+									const int jidx = jpl_base0 + (G == 64 ? __mul24(ss0, wpj * NL) : 0) +
+									                 pidx<PTRLDS, KG>(imax((((cj - 1) + ln0) >> 2) - q, 0), r0 >> 2, glane + ln0, NL);
+									idx = inJ ? jidx : idx;
+									sh[q] = inJ ? 16 * h + cell_shift<4>(r0 & 3) : sh[q];
+								}
+								w[q] = pm.ld(idx);
+							}
+							if constexpr (JPL) {
+								if (inJ) {
+									/* the row's 16 plane bits in column order (bit 15 = the newest step of block b0), the steps behind the walk's own
+									 * shifted out: the first set bit is the column where J opened -- every column up to it is one JUMP op */
+									constexpr unsigned long long ORD = 0xfbea7362d9c85140ull;   /* nibble {k1,k3,k0,k2} -> {k3,k2,k1,k0}, 16 entries of 4 bits */
+									uint32_t cols = 0;
+#pragma unroll
+									for (int q = 0; q < AHEAD; ++q) cols = (cols << 4) | ((uint32_t)(ORD >> (4 * ((w[q] >> sh[q]) & 15u))) & 15u);
+									const int tk = ((cj - 1) + ln0) & 3;
+									cols = (cols << (16 - 4 * AHEAD + 3 - tk)) & 0xffffu;            /* bit 15 = column cj */
+									const int avail = 4 * AHEAD - (3 - tk);
+									const int lim = imin(imin(avail, cj), l1 + l2 - cnt);
+									const int n = __clz((int)((cols << 16) | 0x8000u));
+									const int steps = n < lim ? n + 1 : lim;
+									if (n < lim) st = 2;
+									for (int x = 0; x < steps; ++x) ops[cnt + x] = 3;
+									cnt += steps; cj -= steps;
+									continue;
+								}
 							}
 							bool go = true;
 #pragma unroll
@@ -798,7 +948,7 @@ __global__ __launch_bounds__(64, AT_WAVES16(G, K)) void at_sweep16(const Sweep16
 									if (st == 3) { st = (nb & 4u) ? 3 : 2; op = 1; --ci; }
 									else if (st == 2) { st = (int)(nb & 3u); op = 0; --ci; --cj; }
 									else if (st == 1) { st = (TS == 4 ? (nb & 8u) != 0 : (nb & 8u) == 0) ? 2 : 1; op = 2; --cj; }
-									else if (HASJ) { st = (nb & 16u) ? 2 : 0; op = 3; --cj; }   /* jump state :579-583 */
+									else if (HASJ && !JPL) { st = (nb & 16u) ? 2 : 0; op = 3; --cj; }   /* jump state :579-583 (byte cells) */
 									else { ok = false; go = false; }
 									if (ok) {
 										ops[cnt++] = (uint8_t)op;
@@ -852,6 +1002,36 @@ __global__ __launch_bounds__(64, AT_WAVES16(G, K)) void at_sweep16(const Sweep16
 			if (TB && AT_WALK_PRIO) __builtin_amdgcn_s_setprio(0);
 		}
 		mem.sync();
+	}
+	return wnext;
+}
+
+/* The items that finish a batch of narrow-group items: two groups of 32 lanes (4 alignments), rows per lane for the longest read of
+ * the main items' class in one strip.  (One 64-lane group makes the shortest items -- C2's sliver done in 34 us instead of 42 -- but
+ * needs 2.3 times the instructions per alignment where 32-lane groups need 1.4 times: a caller who keeps launches in flight, whose
+ * next batch would have filled the idle SIMDs anyway, paid 1.5 % for it on C2.) */
+constexpr int AT_TAIL_G = 32;
+constexpr int at_tail_k(int g, int k)
+{
+	return (g * k + AT_TAIL_G - 1) / AT_TAIL_G < 2 ? 2 : (g * k + AT_TAIL_G - 1) / AT_TAIL_G;
+}
+
+/* The kernel.  `a`: the batch.  Kernels with narrow groups (G <= 16: 8 .. 32 alignments per work item, items of ~100 us) also take
+ * `t`: the SLIVER of the batch behind its whole rounds of work items, as items of two 32-lane groups (four alignments, a third as
+ * long) that follow the main items in the same work queue -- a launch that has the chip to itself then ends with a fifth of the
+ * SIMDs busy for a short item instead of a tenth of them working through one long item more (C2: 6 250 items of 16 pairs on 2 048
+ * resident waves = 3.05 rounds).  t.npairs = 0: no sliver.  Other kernels ignore `t`. */
+template <int MODE, int G, int K, int TS, bool SMALL, bool PTRLDS, bool TB, bool RAG = false, int BITS = 2>
+__global__ __launch_bounds__(64, AT_WAVES16(G, K)) void at_sweep16(const Sweep16Args a, const Sweep16Args t)
+{
+	if (a.only_if && __builtin_amdgcn_readfirstlane(*a.only_if) != a.only_val) return;
+	long long w = sweep16_items<MODE, G, K, TS, SMALL, PTRLDS, TB, RAG, BITS>(a, (long long)blockIdx.x, 0);
+	if constexpr (G <= 16 && !RAG && MODE != K_OVERLAP) {
+		if (t.npairs > 0) {
+			constexpr int NGm = 64 / G;
+			const long long nmain = (a.npairs + 2 * NGm - 1) / (2 * NGm);
+			sweep16_items<MODE, AT_TAIL_G, at_tail_k(G, K), TS, SMALL, PTRLDS, TB, false, BITS>(t, w, nmain);
+		}
 	}
 }
 

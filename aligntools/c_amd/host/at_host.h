@@ -24,5 +24,6 @@ void at_reader_close(at_reader *r);
 void at_chunk_reset(at_chunk *c);                      /* forget the records, keep the memory */
 void at_chunk_free(at_chunk *c);
 at_handle *at_host_handle(void);   /* process-wide handle, created on first use; dies without a GPU */
+int at_host_handle_exists(void);   /* has this process created it? */
 
 #endif

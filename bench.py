@@ -47,26 +47,57 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0   # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
-PROFILE_ROUND = "r02"   # profiles/<round>/traffic_<workload>.json, valu_issue.json: the counters the roofline is priced with
+PROFILE_ROUND = "r03"   # profiles/<round>/traffic_<workload>.json, valu_issue.json: the counters the roofline is priced with
 
 
-def valu_roofline(workload, pairs, tb, kernel_config, steps, elapsed):
+def _traffic(workload, tb):
+    try:
+        return json.load(open(os.path.join(ROOT, "profiles", PROFILE_ROUND, "traffic_%s%s.json" % (workload, "" if tb else "_scores"))))
+    except Exception:
+        return None
+
+
+def valu_roofline(workload, pairs, tb, kernel_config, steps, elapsed, cells_per_pair, src_sha):
     """The binding roofline of this path is VALU issue (integer add/max on packed int16: no HBM or MFMA bound comes near,
     DESIGN.md section 4).  achieved = SQ_INSTS_VALU of one launch (rocprofv3 --pmc on this workload and kernel
     configuration, profiles/<round>/traffic_<W>[_scores].json) x launches / timed seconds; peak = SIMDs x clock / cycles per
     wave64 instruction, both measured by tools/valu_issue.hip on the MI355X (profiles/<round>/valu_issue.json: the packed
     16-bit, bit-field and DPP instructions the step body is made of occupy a SIMD for 4 cycles, and so does everything
-    else once it is mixed with them; the clock is what the chip held under that load, not the nominal 2.4 GHz)."""
-    try:
-        prof = json.load(open(os.path.join(ROOT, "profiles", PROFILE_ROUND, "traffic_%s%s.json" % (workload, "" if tb else "_scores"))))
-        vi = json.load(open(os.path.join(ROOT, "profiles", PROFILE_ROUND, "valu_issue.json")))
-    except Exception:
+    else once it is mixed with them; the clock is what the chip held under that load, not the nominal 2.4 GHz).
+
+    The counters belong to ONE state of the kernels: they are used only if the profile carries the fingerprint of today's
+    kernel sources (aligntools.c_amd.kernel_source_sha16), the same kernel configuration string and the same batch size --
+    otherwise achieved / peak / frac are null and `stale` says why.
+
+    `frac` prices an instruction at the 4-cycle class this repository measured; MI355X_MICROARCH.md documents only the 2-cycle
+    class of plain VOP2 integer adds, and `frac_at_documented_2_cycles` is the same quotient against that nominal rate.  What
+    neither fraction shows -- a kernel with twice the instructions would score the same -- is in `insts_per_cell` and
+    `insts_per_alignment`, with the scores-only kernel's figures beside them (the instructions a traceback costs)."""
+    prof = _traffic(workload, tb)
+    vi = vi_src = None
+    for rnd in (PROFILE_ROUND, "r02"):   # the issue rates are a property of the chip: measured in round 2, measured again when a round re-runs tools/valu_issue.hip
+        try:
+            vi_src = "profiles/%s/valu_issue.json" % rnd
+            vi = json.load(open(os.path.join(ROOT, vi_src)))
+            break
+        except Exception:
+            vi = None
+    if prof is None or vi is None:
         return None, None
     insts = (prof.get("sq_counters_per_launch") or {}).get("SQ_INSTS_VALU")
     traffic = prof.get("hbm_bytes_per_launch")
-    # the counters belong to one kernel configuration and batch size: another one (AT_GROUP, --pairs, --l1 ...) has no roofline
-    if not insts or prof.get("kernel_config") != kernel_config or prof.get("pairs") != pairs:
-        return None, traffic
+    stale = None
+    if not insts:
+        stale = "no SQ_INSTS_VALU in the profile"
+    elif prof.get("kernel_source_sha16") != src_sha:
+        stale = "kernel sources changed since the counters were collected (profile %s, sources %s)" % (prof.get("kernel_source_sha16"), src_sha)
+    elif prof.get("kernel_config") != kernel_config:
+        stale = "another kernel configuration (AT_GROUP, --l1 ...)"
+    elif prof.get("pairs") != pairs:
+        stale = "another batch size"
+    if stale:
+        return dict(bound="valu", achieved=None, peak=None, unit="G wave-instr/s", frac=None, stale=stale,
+                    source="profiles/%s/traffic_%s%s.json" % (PROFILE_ROUND, workload, "" if tb else "_scores")), None
     # packed int16 kernels: every instruction of the step body is of the 4-cycle class; int32 kernels: mostly 2-cycle adds, priced
     # with the full-rate 2.0 (the only bound that holds for any mix)
     cyc = vi["roofline"]["cycles_per_inst"]["packed16" if "packed16" in kernel_config else "int32"]
@@ -74,9 +105,19 @@ def valu_roofline(workload, pairs, tb, kernel_config, steps, elapsed):
     simds = vi["roofline"]["simds"]
     peak = simds * ghz / cyc                      # G wave-instructions / s
     achieved = insts * steps / elapsed / 1e9
-    return dict(bound="valu", achieved=achieved, peak=peak, unit="G wave-instr/s", frac=achieved / peak,
-                valu_insts_per_launch=insts, cycles_per_inst=cyc, clock_ghz=ghz, simds=simds,
-                source="profiles/%s/traffic_%s%s.json + valu_issue.json" % (PROFILE_ROUND, workload, "" if tb else "_scores")), traffic
+    out = dict(bound="valu", achieved=achieved, peak=peak, unit="G wave-instr/s", frac=achieved / peak,
+               frac_at_documented_2_cycles=achieved / (simds * ghz / 2.0),
+               valu_insts_per_launch=insts, cycles_per_inst=cyc, cycles_per_inst_source=vi_src + " (this repository's microbenchmark tools/valu_issue.hip; "
+               "MI355X_MICROARCH.md documents the 2-cycle class only)", clock_ghz=ghz, simds=simds,
+               insts_per_alignment=insts / pairs, insts_per_cell=insts / (pairs * cells_per_pair), kernel_source_sha16=src_sha,
+               source="profiles/%s/traffic_%s%s.json + %s" % (PROFILE_ROUND, workload, "" if tb else "_scores", vi_src))
+    other = _traffic(workload, not tb)
+    oi = ((other or {}).get("sq_counters_per_launch") or {}).get("SQ_INSTS_VALU")
+    if oi and other.get("kernel_source_sha16") == src_sha and other.get("pairs") == pairs:
+        key = "scores_only" if tb else "with_tracebacks"
+        out["insts_per_alignment_" + key] = oi / pairs
+        out["insts_per_cell_" + key] = oi / (pairs * cells_per_pair)
+    return out, traffic
 
 WORKLOADS = {
     # name: (mode, l1, l2, pairs per GPU, scoring m,u,o,e,j, use_jump, sites, seed)
@@ -87,6 +128,11 @@ WORKLOADS = {
     # all-vs-all over 50k reads of 1 kbp (1.25e9 ordered pairs in full): each step scores a 100k-pair slice of the
     # triangle per GPU, pairs enumerated on the GPU (at_align_allpairs_device), scores + end cells only
     "C5all": ("overlap", 1000, 1000, 100000, (1, -2, -5, -1, -10), False, [], 0x5EED0005),
+    # BASELINE configs[3] and [4] at the sizes they state, on ONE GPU (SURVEY.md 8(d) quotes them for 8): 10 M fit pairs in one launch per
+    # step; the whole 50 000-read triangle (1 249 975 000 pairs) per step, in slices of 8 Mi pairs through at_align_allpairs_device.
+    # Minutes per run: `--workload C4full --steps 5 --warmup 1`, `--workload C5full --steps 1 --warmup 0 --streams 1`
+    "C4full": ("fit", 150, 500, 10000000, (2, -2, -5, -1, -10), True, [100, 200, 300, 400], 0x5EED0004),
+    "C5full": ("overlap", 1000, 1000, 8 << 20, (1, -2, -5, -1, -10), False, [], 0x5EED0005),
     # edit distance with unit mismatch cost (`edit -u 1`): the bit-parallel kernel; "cells" are the DP cells it stands for
     "E1k": ("edit", 1000, 1000, 100000, (1, 1, -5, -1, -10), False, [], 0x5EED0006),
     "E150": ("edit", 150, 150, 400000, (1, 1, -5, -1, -10), False, [], 0x5EED0007),
@@ -254,21 +300,48 @@ def main():
     streams = [torch.cuda.Stream(device=dev) for _ in range(S)] if S > 1 else [torch.cuda.current_stream()]
 
     # ---- this rank's shard of the synthetic batch, packed, resident in HBM ----
-    allpairs = args.workload == "C5all"
+    allpairs = args.workload in ("C5all", "C5full")
+    full_triangle = args.workload == "C5full"
+    ACGT = np.frombuffer(b"ACGT", dtype=np.uint8)
+    from aligntools.c_amd.synth import workload_codes_torch, pack2_torch
     if allpairs:
         nreads = 50000
         blob = synth_pairs_blob(seed, nreads // 2, l1, l2)           # 25k rows of two 1 kbp reads
         plist = [(row[k * l1:(k + 1) * l1].tobytes(), b"") for row in blob for k in range(2)]
-    else:
+        words, woff1, woff2, len1, len2, bits = A.pack_pairs(plist, bits=args.bits)
+        d_words = torch.from_numpy(words.view(np.int32)).to(dev)
+        d_woff1, d_woff2, d_len1, d_len2 = (torch.from_numpy(x).to(dev) for x in (woff1, woff2, len1, len2))
+        sample_rows = {}
+    elif args.bits == 8:
         blob = workload_blob(mode, use_jump, seed, pairs, l1, l2, first_pair=rank * pairs)   # (C4: every other read is a mutated window of its contig)
         plist = [(row[:l1].tobytes(), row[l1:].tobytes()) for row in blob]
-    words, woff1, woff2, len1, len2, bits = A.pack_pairs(plist, bits=args.bits)
+        words, woff1, woff2, len1, len2, bits = A.pack_pairs(plist, bits=args.bits)
+        d_words = torch.from_numpy(words.view(np.int32)).to(dev)
+        d_woff1, d_woff2, d_len1, d_len2 = (torch.from_numpy(x).to(dev) for x in (woff1, woff2, len1, len2))
+        sample_rows = {k: plist[k] for k in range(0, pairs, max(1, pairs // 64))}
+    else:
+        # generated and packed where it is used, in HBM (aligntools/c_amd/synth.py: the torch forms are bit-identical to the numpy
+        # generators, tests/test_synth.py): 10 M pairs take seconds here and a quarter of an hour in numpy
+        bits = 2
+        w1, w2 = (l1 + 15) // 16 + 1, (l2 + 15) // 16 + 1
+        d_words = torch.zeros(pairs * (w1 + w2) + 4, dtype=torch.int32, device=dev)
+        wv = d_words[:pairs * (w1 + w2)].view(pairs, w1 + w2)
+        sample_rows, want = {}, set(range(0, pairs, max(1, pairs // 64)))
+        for lo in range(0, pairs, 500000):
+            nn = min(500000, pairs - lo)
+            c = workload_codes_torch(mode, use_jump, seed, nn, l1, l2, rank * pairs + lo, dev)   # (C4: every other read is a mutated window of its contig)
+            wv[lo:lo + nn, :w1] = pack2_torch(c[:, :l1])
+            wv[lo:lo + nn, w1:] = pack2_torch(c[:, l1:])
+            for k in sorted(x for x in want if lo <= x < lo + nn):
+                row = ACGT[c[k - lo].cpu().numpy()]
+                sample_rows[k] = (row[:l1].tobytes(), row[l1:].tobytes())
+            del c
+        d_woff1 = torch.arange(pairs, dtype=torch.int64, device=dev) * (w1 + w2)
+        d_woff2 = d_woff1 + w1
+        d_len1 = torch.full((pairs,), l1, dtype=torch.int32, device=dev)
+        d_len2 = torch.full((pairs,), l2, dtype=torch.int32, device=dev)
+    words_nbytes = d_words.numel() * 4
     tb = (not args.no_traceback) and mode != "edit" and not allpairs
-    d_words = torch.from_numpy(words.view(np.int32)).to(dev)
-    d_woff1 = torch.from_numpy(woff1).to(dev)
-    d_woff2 = torch.from_numpy(woff2).to(dev)
-    d_len1 = torch.from_numpy(len1).to(dev)
-    d_len2 = torch.from_numpy(len2).to(dev)
     ops_off = np.arange(pairs, dtype=np.int64) * (l1 + l2)
     d_ops_off = torch.from_numpy(ops_off).to(dev)
     # score, end_i, end_j, state, nops (the CIGAR lengths) of a step: [5, pairs] int32.
@@ -320,14 +393,27 @@ def main():
         allpay = [None] * NGB                              # (sized on first use)
         pay_pad = [0] * NGB
 
+    tri_sum = torch.zeros(NB, dtype=torch.int64, device=dev)   # C5full: sum of the scores of the triangle, per buffer set
+
     def step(k):
         d_res = res_of(k)
+        if full_triangle:
+            tri_sum[k % NB] = 0
         al, d_ops = als[k % S], ops_of(k)
         stream = torch.cuda.current_stream().cuda_stream
         if gath:   # the collectives of the group that last used this buffer set must be done before a step writes into it
             for wk in busy[grp_of[k] % NGB]:
                 wk.wait()
-        if allpairs:   # this rank's slice of the triangle, a different one every step
+        if full_triangle:   # the whole triangle (this rank's contiguous share of it), slice after slice into the same result buffers
+            tri = nreads * (nreads - 1) // 2
+            lo_r, hi_r = (tri * rank + world - 1) // world, min(tri, (tri * (rank + 1) + world - 1) // world)
+            for first in range(lo_r, hi_r, pairs):
+                nn = min(pairs, hi_r - first)
+                al.align_allpairs_device(A.MODES[mode], nreads, d_words.data_ptr(), bits, d_woff1.data_ptr(), d_len1.data_ptr(), l1,
+                                         first, nn, False, d_res[0].data_ptr(), d_res[1].data_ptr(), d_res[2].data_ptr(),
+                                         d_res[3].data_ptr(), None, None, None, stream)
+                tri_sum[k % NB] += d_res[0, :nn].sum(dtype=torch.int64)      # (every slice's scores are read before the next one overwrites them)
+        elif allpairs:   # this rank's slice of the triangle, a different one every step
             first = ((k * world + rank) * pairs) % (nreads * (nreads - 1) // 2 - pairs)
             al.align_allpairs_device(A.MODES[mode], nreads, d_words.data_ptr(), bits, d_woff1.data_ptr(), d_len1.data_ptr(), l1,
                                      first, pairs, False, d_res[0].data_ptr(), d_res[1].data_ptr(), d_res[2].data_ptr(),
@@ -453,14 +539,14 @@ def main():
     kern_avg_ms = sum(kern_ms) / len(kern_ms)
     # the same launch with nothing else in flight (what a rocprofv3 trace of `--streams 1` shows)
     iso = []
-    for k in range(4):
+    for k in range(0 if full_triangle else 4):   # (a step of C5full is the whole triangle, minutes long: its timed steps were alone already)
         ea, eb = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         ea.record()
         step(args.steps - 1)   # the last step again, into the same buffers
         eb.record()
         torch.cuda.synchronize()
         iso.append(ea.elapsed_time(eb))
-    kern_iso_ms = min(iso)
+    kern_iso_ms = min(iso) if iso else kern_ms[0]
     # every step of the timed run holds the results of the same batch
     last = args.steps - 1
     if not allpairs and args.steps > 0:   # (all-vs-all sweeps a different slice of the triangle every step)
@@ -501,24 +587,26 @@ def main():
         h_r2 = d_r2s[last % S].cpu().numpy().tobytes()
         h_ops = d_ops[:slot_bytes].cpu().numpy()
         h_res = res_of(last).cpu().numpy()
-        for k in range(0, pairs, max(1, pairs // 64)):
+        for k in sorted(sample_rows):
             oo, nk = int(ops_off[k]), int(nops[k])
-            a, b = al.render(h_ops[oo:oo + nk].tobytes(), plist[k][0], int(h_res[1][k]), plist[k][1], int(h_res[2][k]))
+            a, b = al.render(h_ops[oo:oo + nk].tobytes(), sample_rows[k][0], int(h_res[1][k]), sample_rows[k][1], int(h_res[2][k]))
             assert a.encode("latin1") == h_r1[oo:oo + nk] and b.encode("latin1") == h_r2[oo:oo + nk], "rendered strings differ"
     cells_per_step = float(pairs) * l1 * l2 * world
+    if full_triangle:
+        cells_per_step = float(nreads * (nreads - 1) // 2) * l1 * l2     # the whole triangle, whatever the number of ranks (strong scaling)
     gcups = cells_per_step * args.steps / elapsed / 1e9
     # algorithmic HBM bytes of one launch on one GPU
-    bytes_in = words.nbytes + pairs * (8 + 8 + 4 + 4) + (pairs * 8 if tb else 0)
+    bytes_in = words_nbytes + pairs * (8 + 8 + 4 + 4) + (pairs * 8 if tb else 0)
     bytes_out = pairs * 16 + (pairs * 4 + int(nops.sum()) if tb else 0)
     achieved = (bytes_in + bytes_out) / (kern_avg_ms * 1e-3) / 1e9
-    valu, traffic = valu_roofline(args.workload, pairs, tb, al.last_config, args.steps, elapsed)
+    valu, traffic = valu_roofline(args.workload, pairs, tb, al.last_config, args.steps, elapsed, float(l1) * l2, A.kernel_source_sha16())
 
     if rank == 0:
         out = {
             "metric": "GCUPS (DP cell updates/s), SW affine-gap 150bp pairs" if args.workload == "C2"
                       else "GCUPS (DP cell updates/s), %s %dx%d" % (mode, l1, l2),
             "value": gcups, "unit": "GCUPS", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+            "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "strong" if full_triangle else "weak",
             "vs_baseline": None, "dtype": "int16" if "packed16" in al.last_config else "int32", "data": "synthetic",
             "config": {"workload": "%s: %s %s, %d x (%dx%d bp) pairs per GPU, uniform ACGT, m=%d u=%d o=%d e=%d%s, "
                                    "%s" % (args.workload, mode, "linear-gap" if mode == "overlap" else "unit-gap" if mode == "edit" else "affine-gap", pairs, l1, l2,
@@ -533,7 +621,7 @@ def main():
                              kernel=("at_sweep16" if "packed16" in al.last_config else "at_myers" if "myers" in al.last_config else "at_sweep") + "<%s>" % mode,
                              kernel_avg_ms=kern_avg_ms, kernel_min_ms=kern_ms[0], kernel_alone_ms=kern_iso_ms, launches_in_flight=S,
                              host_issue_ms_per_step=(t_issued - t0) * 1e3 / max(1, args.steps),
-                             gcups_one_launch_at_a_time=float(pairs) * l1 * l2 / (kern_iso_ms * 1e-3) / 1e9,
+                             gcups_one_launch_at_a_time=cells_per_step / world / (kern_iso_ms * 1e-3) / 1e9,
                              # the HBM view BASELINE.json asks for: ALGORITHMIC bytes of a launch over its HIP-event duration
                              hbm={"achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                                   "achieved_aggregate": (bytes_in + bytes_out) * args.steps / elapsed / 1e9,

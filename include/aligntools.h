@@ -70,6 +70,31 @@ double align_fit_affine_jump(kstring_t *s1, kstring_t *s2, kstring_t *r1, kstrin
 double align_overlap(kstring_t *s1, kstring_t *s2, kstring_t *r1, kstring_t *r2, opt_t *opt);
 int edit_dist(kstring_t *s1, kstring_t *s2, opt_t *opt);
 
+/*
+ * The traceback half of the surface: trace_back_gla :372, trace_back_fit_affine_jump :558, trace_back_local_affine :766,
+ * trace_back_overlap :896 -- same names and argument order.  In the reference they walk the eight host matrices of a
+ * matrix_t that only the fill loops inside align_*() can produce.  Here the pointer matrix never leaves the GPU and the
+ * walk runs in the kernel that filled it, so matrix_t is opaque: it is what a fill left behind -- end cell, start state
+ * and the walk's ops -- and comes from at_fill_matrix(), the fill half of align_*() as a call of its own:
+ *
+ *     matrix_t *S = at_fill_matrix(AT_FILL_LOCAL, s1, s2, opt, &score, &state, &i, &j);   // create_matrix + fill + end cell
+ *     trace_back_local_affine(S, s1, s2, r1, r2, i, j);                                   // r1 / r2 as align_*() leaves them
+ *     destory_matrix(S);                                                                  // alignment.h:153 (sic)
+ *
+ * The walk exists for the fill's own end cell only: a trace_back_*() call with another (state, i, j) dies ("FATAL ERROR",
+ * rc 255) instead of walking a matrix that is not there.  align_*() = these three calls.
+ */
+typedef struct at_matrix matrix_t;
+enum { AT_FILL_GLOBAL = 0, AT_FILL_LOCAL = 1, AT_FILL_FIT = 2, AT_FILL_OVERLAP = 3 };
+/* the reference's state codes (alignment.h:27-34), as trace_back_gla / trace_back_fit_affine_jump take them */
+enum { AT_LOW = 500, AT_MID = 600, AT_UPP = 700 };
+matrix_t *at_fill_matrix(int fill_mode, kstring_t *s1, kstring_t *s2, opt_t *opt, double *score, int *state, int *i, int *j);
+void destory_matrix(matrix_t *S);
+void trace_back_gla(matrix_t *S, kstring_t *s1, kstring_t *s2, kstring_t *res_ks1, kstring_t *res_ks2, int state);
+void trace_back_fit_affine_jump(matrix_t *S, kstring_t *s1, kstring_t *s2, kstring_t *res_ks1, kstring_t *res_ks2, int state, int i, int j);
+void trace_back_local_affine(matrix_t *S, kstring_t *s1, kstring_t *s2, kstring_t *res_ks1, kstring_t *res_ks2, int i, int j);
+void trace_back_overlap(matrix_t *S, kstring_t *ks1, kstring_t *ks2, kstring_t *res_ks1, kstring_t *res_ks2, int i, int j);
+
 /* kstring_read (alignment.h:217-262): exactly two FASTA/FASTQ records (plain or
  * gzip) into str1/str2; with opt->s == AT_TRUE also the junction sites from the
  * record comment, echoing the comment to stdout like the reference (:249). */

@@ -5,7 +5,8 @@
  *
  *   abi_consumer nogpu   host-only entry points; at_init must fail loudly (no CPU fallback)
  *   abi_consumer gpu     the reference's C1 case (test/test_local.fa: local -m 2 -u -2 -o -5 -e -2 -> 4, LEA / MEA)
- *                        through at_align_batch + at_render, at_align_batch_strings and align_local_affine
+ *                        through at_align_batch + at_render, at_align_batch_strings, align_local_affine and the fill /
+ *                        trace_back_*() pair of calls
  */
 #include <stdio.h>
 #include <stdlib.h>
@@ -83,6 +84,30 @@ static int with_gpu(void)
 		q1->s = (char *)calloc(s1->l + s2->l + 1, 1); q2->s = (char *)calloc(s1->l + s2->l + 1, 1);
 		sc = align_local_affine(s1, s2, q1, q2, opt);
 		CHECK(sc == 4.0 && strcmp(q1->s, "LEA") == 0 && strcmp(q2->s, "MEA") == 0 && q1->l == 3);
+		{   /* the fill and the traceback as two calls, the way align_local_affine is written (alignment.h:814-845) */
+			double sc2; int state = 0, i = 0, j = 0;
+			matrix_t *S = at_fill_matrix(AT_FILL_LOCAL, s1, s2, opt, &sc2, &state, &i, &j);
+			CHECK(S != NULL && sc2 == 4.0 && state == AT_MID && i == 6 && j == 3);
+			free(q1->s); free(q2->s);
+			q1->s = (char *)calloc(s1->l + s2->l + 1, 1); q2->s = (char *)calloc(s1->l + s2->l + 1, 1);
+			trace_back_local_affine(S, s1, s2, q1, q2, i, j);
+			CHECK(strcmp(q1->s, "LEA") == 0 && strcmp(q2->s, "MEA") == 0 && q2->l == 3);
+			destory_matrix(S);
+			S = at_fill_matrix(AT_FILL_GLOBAL, s1, s2, opt, &sc2, &state, &i, &j);
+			trace_back_gla(S, s1, s2, q1, q2, state);
+			CHECK(q1->l == 6 && q2->l == 6 && i == 6 && j == 3);
+			destory_matrix(S);
+			S = at_fill_matrix(AT_FILL_OVERLAP, s1, s2, opt, &sc2, &state, &i, &j);
+			trace_back_overlap(S, s1, s2, q1, q2, i, j);
+			CHECK(q1->l == q2->l);
+			destory_matrix(S);
+			{   /* fit wants l1 <= l2 */
+				matrix_t *F = at_fill_matrix(AT_FILL_FIT, s2, s1, opt, &sc2, &state, &i, &j);
+				trace_back_fit_affine_jump(F, s2, s1, q1, q2, state, i, j);
+				CHECK(q1->l == q2->l && q1->l >= 3 && i == 3);
+				destory_matrix(F);
+			}
+		}
 		opt->u = 1;                                           /* -u is the mismatch COST of edit (alignment.h:294) */
 		CHECK(edit_dist(s1, s2, opt) == 4);
 		free(s1->s); free(s2->s); free(q1->s); free(q2->s); free(s1); free(s2); free(q1); free(q2); free(opt);

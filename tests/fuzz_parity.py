@@ -17,18 +17,20 @@ ALPHABETS = ["ACGT", "ACGT", "ACGT", "AC", "A", "ACGTN", "ACDEFGHIKLMNPQRSTVWY",
 
 
 def draw_batch(rng):
-    mode = rng.choice(["global", "local", "fit", "fit", "overlap", "edit"])
+    only = os.environ.get("AT_FUZZ_MODES")          # e.g. "fitj,overlap": a campaign aimed at those kernels
+    mode = rng.choice(only.split(",") if only else ["global", "local", "fit", "fit", "overlap", "edit"])
     sc = rng.choice(SCORINGS)
     alpha = rng.choice(ALPHABETS)
-    uj = mode == "fit" and rng.random() < 0.5
+    uj = (mode == "fit" and rng.random() < 0.5) or mode == "fitj"
+    mode = "fit" if mode == "fitj" else mode
     n = rng.choice([1, 2, 3, 7, 16, 33, 64, 100])
     big = rng.random() < 0.06
     hi = 1500 if big else rng.choice([8, 40, 70, 130, 200, 330, 650])   # (650: the 12- to 19-row classes of the 32-lane groups)
+    uniform = rng.random() < 0.5
     if big:
         n = min(n, 7)
     elif hi == 650:
-        n = min(n, 16)
-    uniform = rng.random() < 0.5
+        n = min(n, 16) if uniform or rng.random() < 0.5 else 64 + n % 8   # (64 pairs and more: ragged batches of long reads go to the 32-lane frames / the ragged packed overlap)
     if uniform:
         l1 = rng.randint(1, hi)
         l2 = rng.randint(max(l1, 2) if mode == "fit" else 1, max(l1, 2) + hi if mode == "fit" else hi)
@@ -64,7 +66,20 @@ def draw_batch(rng):
     return mode, sc, uj, sites, pairs, rng.random() < 0.8
 
 
-def run(cases, seed, al=None, verbose=True):
+def kernel_class(cfg):
+    """The kernel class a batch ran on, from at_last_config: e.g. "packed16x16 8x8 K19 tb", "packed16x4 1x64 K16 ragged tb" (overlap),
+    "int32", "myers" -- what a campaign has covered."""
+    import re
+    if "myers" in cfg:
+        return "myers"
+    m = re.search(r"packed16 x(\d+) bits=(\d) (\d+)x(\d+)-lane groups.*?rows/lane=(\d+)", cfg)
+    if not m:
+        return "int32"
+    return "packed16x%s %sx%s K%s%s%s%s" % (m.group(1), m.group(3), m.group(4), m.group(5), " ragged" if "ragged frames" in cfg else "",
+                                          " hbm-ptr" if "hbm-pointers" in cfg else "", " +sliver" if "32-lane items" in cfg else "")
+
+
+def run(cases, seed, al=None, verbose=True, classes=None):
     import aligntools.c_amd as A
     own = al is None
     if own:
@@ -83,6 +98,8 @@ def run(cases, seed, al=None, verbose=True):
                 assert any(O.align(O.MODE_NAMES[mode], a, b, *sc, uj, sites)["rc"] != 0 for a, b in pairs), (mode, sc, pairs[:2])
             batches += 1
             continue
+        if classes is not None:
+            classes[(mode + ("j" if uj else "")) + " " + kernel_class(al.last_config)] = classes.get((mode + ("j" if uj else "")) + " " + kernel_class(al.last_config), 0) + 1
         for k, (a, b) in enumerate(pairs):
             r = O.align(O.MODE_NAMES[mode], a, b, *sc, uj, sites)
             ctx = (seed, batches, mode, sc, uj, sites, k, a, b, al.last_config)
@@ -110,4 +127,6 @@ def run(cases, seed, al=None, verbose=True):
 
 if __name__ == "__main__":
     os.environ.setdefault("AT_PACKED_MIN_ROUNDS", "0")   # small batches must still reach the 64-lane packed kernels
-    run(int(sys.argv[1]) if len(sys.argv) > 1 else 20000, int(sys.argv[2]) if len(sys.argv) > 2 else 1)
+    seen = {}
+    run(int(sys.argv[1]) if len(sys.argv) > 1 else 20000, int(sys.argv[2]) if len(sys.argv) > 2 else 1, classes=seen)
+    print("kernel classes:", "; ".join("%s (%d)" % kv for kv in sorted(seen.items())))

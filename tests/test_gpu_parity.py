@@ -626,7 +626,7 @@ def test_ragged_local_batches_in_frames(al, maxl):
                 if tb:
                     assert res["ops"][k] == r["ops"], (sc, k)
     al.set_scoring(2, -2, -5, -2)
-    longer = pairs[:200] + [(dna(305), dna(100))]
+    longer = pairs[:200] + [(dna(609), dna(100))]          # (305 .. 608 bases: the 32-lane frames, test_ragged_long_reads_in_32_lane_frames)
     res = al.align_batch("local", longer, render=False)
     assert "int32" in al.last_config
     r = O.align(O.LOCAL, longer[-1][0], longer[-1][1], 2, -2, -5, -2)
@@ -679,11 +679,111 @@ def test_ragged_global_and_fit_batches_in_frames(al, mode):
                     if tb:
                         assert res["ops"][k] == r["ops"], (mode, alpha, sc, k, len(a), len(b))
     al.set_scoring(2, -2, -5, -1, -10, uj, sites)
-    longer = pairs[:200] + [(dna(305), dna(400))]
+    longer = pairs[:200] + [(dna(513), dna(600))]          # (beyond the longest one-strip frame of global, 512, and of fit, 416)
     res = al.align_batch(m, longer, render=False)
     assert "int32" in al.last_config
     r = O.align(O.MODE_NAMES[m], longer[-1][0], longer[-1][1], 2, -2, -5, -1, -10, uj, sites)
     assert int(res["score"][-1]) == r["score"] and res["ops"][-1] == r["ops"]
+
+
+@pytest.mark.parametrize("mode", ["local", "global", "fit", "fitj"])
+def test_ragged_long_reads_in_32_lane_frames(al, mode):
+    """Ragged batches with reads of 305 .. 608 bases (local), .. 512 (global), .. 416 (fit, fit -s) stay on the packed kernels: frames
+    on two groups of 32 lanes, one strip of 32 x 10 / 12 / 13 / 16 / 19 rows, next to the 8- and 16-lane frames of the shorter reads
+    of the same batch.  Lengths on both sides of every class edge, lengths that occur once (padded items), related and unrelated
+    pairs, both alphabets, with and without tracebacks: score / end cell / start state / ops against the oracle."""
+    rng = random.Random(6080 + len(mode))
+    uj = mode == "fitj"
+    m = "fit" if uj else mode
+    top = {"local": 608, "global": 512, "fit": 416, "fitj": 416}[mode]
+    edges = [x for x in (150, 300, 304, 305, 306, 319, 320, 321, 383, 384, 385, 415, 416, 417, 500, 511, 512, 513, 600, 607, 608) if x <= top]
+    for alpha in ("ACGT", "ACGTN"):
+        dna = lambda n: "".join(rng.choice(alpha) for _ in range(n))
+        pairs = []
+        for k in range(260 if alpha == "ACGT" else 120):
+            l1 = rng.choice(edges) if k % 3 else rng.randint(250, top)
+            l2 = rng.randint(max(l1, 2), max(l1, 2) + rng.choice([0, 7, 90])) if m == "fit" else rng.randint(max(1, l1 - 120), l1 + 120)
+            a = dna(l1)
+            if k % 2:
+                t = list(a)
+                for _ in range(max(1, l1 // 20)):
+                    q = rng.randrange(len(t))
+                    r = rng.random()
+                    if r < 0.4:
+                        t[q] = rng.choice(alpha)
+                    elif r < 0.7 and len(t) > 1:
+                        del t[q]
+                    else:
+                        t.insert(q, rng.choice(alpha))
+                b = (dna(rng.randint(0, 20)) + "".join(t) + dna(l2))[:l2]
+            else:
+                b = dna(l2)
+            pairs.append((a, b))
+        sites = [20, 100, 250, 400]
+        # (global and fit matrices drift downwards: at 500 bases only mild scorings keep 16 x the score range inside 16 bits, packed_ok)
+        sc = (2, -2, -5, -1, -10) if mode == "local" and alpha == "ACGTN" else (1, -1, -2, -1, -4)
+        al.set_scoring(*sc, uj, sites)
+        for tb in (True, False):
+            res = al.align_batch(m, pairs, traceback=tb, render=False)
+            assert "ragged frames" in al.last_config, al.last_config
+            for k, (a, b) in enumerate(pairs):
+                r = O.align(O.MODE_NAMES[m], a, b, *sc, uj, sites)
+                assert (int(res["score"][k]), int(res["end_i"][k]), int(res["end_j"][k]), int(res["state"][k])) == \
+                       (r["score"], r["end_i"], r["end_j"], r["state"]), (mode, alpha, tb, k, len(a), len(b))
+                if tb:
+                    assert res["ops"][k] == r["ops"], (mode, alpha, k, len(a), len(b))
+        # every pair long: the launch itself names the 32-lane groups
+        longs = [p for p in pairs if len(p[0]) > 304]
+        res = al.align_batch(m, longs, render=False)
+        assert "2x32-lane groups" in al.last_config and "ragged frames" in al.last_config, al.last_config
+        for k, (a, b) in enumerate(longs[:40]):
+            r = O.align(O.MODE_NAMES[m], a, b, *sc, uj, sites)
+            assert (int(res["score"][k]), res["ops"][k]) == (r["score"], r["ops"]), (mode, alpha, k)
+
+
+def test_ragged_overlap_with_tracebacks_on_the_packed_kernel(al):
+    """Ragged overlap batches with tracebacks (reads of up to 1 024 bases, scores within 16 bits) run on the packed overlap kernel in
+    frames: the two alignments of a wavefront share l1 (the end cells lie in row l1), 4 rows per lane up to 256 bases and 16 beyond,
+    each alignment scanning row l1 up to its own column l2 - 1.  True overlaps with errors, unrelated reads and empty results, both
+    alphabets, against the oracle; without tracebacks, or with a read of 1 025 bases, the batch runs on the int32 kernel."""
+    rng = random.Random(9264)
+    for alpha in ("ACGT", "ACGTN"):
+        dna = lambda n: "".join(rng.choice(alpha) for _ in range(n))
+        pairs = []
+        for k in range(300 if alpha == "ACGT" else 120):
+            l1 = rng.choice([1, 2, 60, 255, 256, 257, 400, 800, 1000, 1023, 1024]) if k % 3 == 0 else rng.randint(1, 1024)
+            l2 = rng.randint(1, 1024)
+            a = dna(l1)
+            if k % 4:
+                ov = rng.randint(1, min(l1, l2))
+                t = list(a[l1 - ov:])
+                for _ in range(ov // 25):
+                    q = rng.randrange(len(t))
+                    x = rng.random()
+                    if x < 0.5:
+                        t[q] = rng.choice(alpha)
+                    elif x < 0.75 and len(t) > 2:
+                        del t[q]
+                    else:
+                        t.insert(q, rng.choice(alpha))
+                b = ("".join(t) + dna(l2))[:l2]
+            else:
+                b = dna(l2)
+            pairs.append((a, b))
+        for sc in ((1, -2, -5, -1), (2, -1, -1, -1)):
+            al.set_scoring(*sc)
+            res = al.align_batch("overlap", pairs, render=False)
+            assert "packed16 x4" in al.last_config and "ragged frames" in al.last_config, al.last_config
+            for k, (a, b) in enumerate(pairs):
+                r = O.align(O.OVERLAP, a, b, *sc)
+                assert (int(res["score"][k]), int(res["end_i"][k]), int(res["end_j"][k]), res["ops"][k]) == \
+                       (r["score"], r["end_i"], r["end_j"], r["ops"]), (alpha, sc, k, len(a), len(b))
+        res = al.align_batch("overlap", pairs, traceback=False)
+        assert "int32" in al.last_config
+        res = al.align_batch("overlap", pairs[:100] + [(dna(1025), dna(30))], render=False)
+        assert "int32" in al.last_config
+        r = O.align(O.OVERLAP, pairs[7][0], pairs[7][1], 2, -1, -1, -1)
+        assert int(res["score"][7]) == r["score"] and res["ops"][7] == r["ops"]
 
 
 def test_chunked_host_entry(al):
@@ -1220,9 +1320,9 @@ def test_packed_8_lane_groups(al, mode):
 
 @pytest.mark.parametrize("mode", ["local", "global", "fit", "fitj"])
 def test_sliver_of_a_batch_on_64_lane_groups(al, mode, monkeypatch):
-    """AT_TAIL_SPLIT=1 (off by default: it pays for lone launches only): a uniform batch that fills the resident waves a whole
-    number of times plus a sliver (less than a third of a round) is split: whole rounds on the 8- or 16-lane groups, the sliver
-    on the 64-lane kernel behind them (at_hip.hip, align_device).
+    """A uniform batch that fills the resident waves a whole number of times plus a sliver (less than a quarter of a round) ends on
+    items of two 32-lane groups: the sliver's pairs follow the 4- / 8- / 16-lane items in the same launch and work queue (the
+    kernel's second argument; at_hip.hip, align_device).  AT_TAIL_SPLIT=0 keeps every pair on the narrow groups.
     The split batch equals the unsplit one everywhere and the oracle on the sliver and on a sample of the rest."""
     import re
     monkeypatch.setenv("AT_HOST_CHUNKS", "1")      # the host entry would cut the batch into chunks side by side: one launch here
@@ -1262,10 +1362,10 @@ def test_sliver_of_a_batch_on_64_lane_groups(al, mode, monkeypatch):
             pairs = (base * (n // 2048 + 1))[:n - 700] + fresh
             monkeypatch.setenv("AT_TAIL_SPLIT", "0")
             whole = al.align_batch(m, pairs, traceback=tb, render=False)
-            assert "64-lane groups" not in al.last_config
+            assert "32-lane items" not in al.last_config
             monkeypatch.setenv("AT_TAIL_SPLIT", "1")
             res = al.align_batch(m, pairs, traceback=tb, render=False)
-            assert "+ last %d pairs on 64-lane groups" % (37 * per_wave - 3) in al.last_config, al.last_config
+            assert "+ last %d pairs as 32-lane items" % (37 * per_wave - 3) in al.last_config, al.last_config
             for key in ("score", "end_i", "end_j", "state"):
                 assert (np.asarray(res[key]) == np.asarray(whole[key])).all(), (mode, l1, key)
             if tb:

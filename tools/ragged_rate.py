@@ -5,6 +5,7 @@ packed kernels in frames -- against uniform batches of the workload's nominal sh
     fit -s  150 x 500 (C4)   vs   100..150 x 400..500
     global  150 x 150        vs   100..150 x 100..150
     local   250 x 250        vs   200..250 x 200..250          global  300 x 300   vs   250..300 x 250..300
+    local / global 500 x 500 vs   400..500 x 400..500          overlap 1000 x 1000 vs  800..1000 x 800..1000   (20k pairs)
 AT_RAGGED_PACKED=0 keeps ragged batches on the int32 kernel (the rate before frames).
 """
 import ctypes as C
@@ -29,10 +30,16 @@ CASES = [
     ("global", (1, -1, -4, -1, -10), False, [], 150, 150, [("uniform 150x150", 150, 150), ("ragged 100..150 x 100..150", 100, 100)]),
     ("local", (2, -2, -5, -2, -10), False, [], 250, 250, [("uniform 250x250", 250, 250), ("ragged 200..250 x 200..250", 200, 200)]),
     ("global", (1, -1, -4, -1, -10), False, [], 300, 300, [("uniform 300x300", 300, 300), ("ragged 250..300 x 250..300", 250, 250)]),
+    # reads of 305 .. 608 bases: frames on the 32-lane groups (round 3); ragged overlap on the packed overlap kernel (n = 20 000)
+    ("local", (2, -2, -5, -2, -10), False, [], 500, 500, [("uniform 500x500", 500, 500), ("ragged 400..500 x 400..500", 400, 400)]),
+    ("global", (1, -1, -4, -1, -10), False, [], 500, 500, [("uniform 500x500", 500, 500), ("ragged 400..500 x 400..500", 400, 400)]),
+    ("overlap", (1, -2, -5, -1, -10), False, [], 1000, 1000, [("uniform 1000x1000", 1000, 1000), ("ragged 800..1000 x 800..1000", 800, 800)]),
 ]
 if len(sys.argv) > 1:   # e.g. `ragged_rate.py 250 300`: only the cases of those read lengths
     CASES = [c for c in CASES if str(c[4]) in sys.argv[1:]]
+N_ALL = n
 for mode, sc, uj, sites, L1, L2, rows in CASES:
+    n = N_ALL if L1 * L2 <= 100000 else N_ALL // 5          # (the long-read cases: 20 000 pairs)
     al.set_scoring(*sc, uj, sites)
     blob = synth_pairs_blob(0x5EED0002, n, L1, L2).reshape(-1).copy()
     off1 = np.arange(n, dtype=np.int64) * (L1 + L2)

@@ -12,8 +12,6 @@
 
 #include <algorithm>
 #include <chrono>
-#include <condition_variable>
-#include <mutex>
 #include <cstdarg>
 #include <cstdio>
 #include <cstdlib>
@@ -51,7 +49,6 @@ struct at_handle {
 	void *hp_blob = nullptr; size_t hp_blob_bytes = 0;
 	void *hp_out = nullptr; size_t hp_out_bytes = 0;
 	void *hp_flag = nullptr;
-	hipEvent_t ev_upload[16] = {};  /* ordered uploads of the chunks of a batch (UploadGate) */
 	double last_payload_per_pair = 16.0;   /* traceback bytes per pair of the latest batch: how much payload the next one fetches unasked */
 	/* all-vs-all in slices: a copy stream, pinned result buffers (two sets, used in turn) and their events */
 	hipStream_t copy_stream = nullptr;
@@ -153,7 +150,6 @@ extern "C" void at_destroy(at_handle *h)
 	if (h->d_scan) (void)hipFree(h->d_scan);
 	if (h->d_rflag) (void)hipFree(h->d_rflag);
 	if (h->h_pin) (void)hipHostFree(h->h_pin);
-	for (int q = 0; q < 16; ++q) if (h->ev_upload[q]) (void)hipEventDestroy(h->ev_upload[q]);
 	if (h->hp_desc) (void)hipHostFree(h->hp_desc);
 	if (h->hp_blob) (void)hipHostFree(h->hp_blob);
 	if (h->hp_out) (void)hipHostFree(h->hp_out);
@@ -918,18 +914,6 @@ static int align_device(at_handle *h, int mode, int64_t npairs,
 	return AT_OK;
 }
 
-/* The chunks of one batch upload IN ORDER: chunk c's copies are queued (on its own stream) behind an event that marks the end of
- * chunk c - 1's, so every chunk crosses the link at its full rate and the first chunk's sweep runs while the others still upload --
- * side by side all uploads end together, late, and all sweeps start then.  The staging copies into page-locked memory before that
- * run on the chunks' threads, in parallel. */
-struct UploadGate {
-	std::mutex mu;
-	std::condition_variable cv;
-	int next = 0;                   /* the chunk whose turn it is to queue its uploads */
-	hipEvent_t done[16] = {};       /* chunk c's uploads have arrived */
-	bool failed = false;
-};
-
 /* AT_HOST_TRACE=1: microseconds since the first call at the stages of the host entry, on stderr (where does a call's time go?) */
 static void htrace(const char *what, long long a)
 {
@@ -947,15 +931,8 @@ static int align_host(at_handle *h, int mode, int64_t npairs, const uint8_t *seq
                       int want_traceback,
                       int32_t *out_score, int32_t *out_end_i, int32_t *out_end_j, int32_t *out_state,
                       uint8_t *out_ops, const int64_t *ops_off, int32_t *out_nops, char *out_r1, char *out_r2,
-                      int64_t pair_base = 0,   /* index of pair 0 in the caller's batch, for messages */
-                      UploadGate *gate = nullptr, int gate_index = 0)
+                      int64_t pair_base = 0)   /* index of pair 0 in the caller's batch, for messages */
 {
-	/* (whatever happens, the chunks behind this one must get their turn) */
-	struct Turn {
-		UploadGate *g; int idx; bool passed = false;
-		void pass() { if (g && !passed) { std::lock_guard<std::mutex> lk(g->mu); g->next = std::max(g->next, idx + 1); passed = true; g->cv.notify_all(); } }
-		~Turn() { pass(); }
-	} turn{gate, gate_index};
 	if (!h) return fail(nullptr, AT_ERR_ARG, "at_align_batch: NULL handle");
 	if (mode < AT_MODE_GLOBAL || mode > AT_MODE_EDIT) return fail(h, AT_ERR_ARG, "unknown mode %d", mode);
 	if (npairs < 0) return fail(h, AT_ERR_ARG, "negative npairs");
@@ -1000,30 +977,30 @@ static int align_host(at_handle *h, int mode, int64_t npairs, const uint8_t *seq
 	 * ---- staging copies run side by side, where the runtime's own pageable path took them one after the other) ---- */
 	auto al = [](size_t x) { return (x + 255) & ~(size_t)255; };
 	const size_t n = (size_t)npairs;
-	/* descriptor block: soff[2n] swoff2[2n] swoff8[2n] opsoff[n] woff1_2[n] woff2_2[n] woff1_8[n] woff2_8[n] (int64) slen[2n] len1[n] len2[n] (int32) */
-	const size_t o_soff = 0, o_sw2 = o_soff + al(2 * n * 8), o_sw8 = o_sw2 + al(2 * n * 8), o_ops = o_sw8 + al(2 * n * 8);
-	const size_t o_w12 = o_ops + al(n * 8), o_w22 = o_w12 + al(n * 8), o_w18 = o_w22 + al(n * 8), o_w28 = o_w18 + al(n * 8);
-	const size_t o_slen = o_w28 + al(n * 8), o_l1 = o_slen + al(2 * n * 4), o_l2 = o_l1 + al(n * 4), desc_bytes = o_l2 + al(n * 4);
-	int rc = grow_pinned(h, &h->hp_desc, &h->hp_desc_bytes, desc_bytes);
+	/* descriptor block, uploaded: soff[2n] swoff[2n] opsoff[n] (int64) slen[2n] (int32) -- per SEQUENCE, s1 of pair k at 2k, s2 at 2k + 1;
+	 * behind it, made on the device (at_split_desc): woff1[n] woff2[n] (int64) len1[n] len2[n] (int32), what the sweep kernels take.
+	 * The word offsets for byte words wait in page-locked memory in case a batch turns out not to be pure ACGT. */
+	const size_t o_soff = 0, o_sw = o_soff + al(2 * n * 8), o_ops = o_sw + al(2 * n * 8), o_slen = o_ops + al(n * 8), up_bytes = o_slen + al(2 * n * 4);
+	const size_t o_w1 = up_bytes, o_w2 = o_w1 + al(n * 8), o_l1 = o_w2 + al(n * 8), o_l2 = o_l1 + al(n * 4), desc_bytes = o_l2 + al(n * 4);
+	int rc = grow_pinned(h, &h->hp_desc, &h->hp_desc_bytes, up_bytes + al(2 * n * 8));
 	if (rc) return rc;
 	char *hd = (char *)h->hp_desc;
-	int64_t *p_soff = (int64_t *)(hd + o_soff), *p_sw2 = (int64_t *)(hd + o_sw2), *p_sw8 = (int64_t *)(hd + o_sw8), *p_ops = (int64_t *)(hd + o_ops);
-	int64_t *p_w12 = (int64_t *)(hd + o_w12), *p_w22 = (int64_t *)(hd + o_w22), *p_w18 = (int64_t *)(hd + o_w18), *p_w28 = (int64_t *)(hd + o_w28);
-	int32_t *p_slen = (int32_t *)(hd + o_slen), *p_l1 = (int32_t *)(hd + o_l1), *p_l2 = (int32_t *)(hd + o_l2);
+	int64_t *p_soff = (int64_t *)(hd + o_soff), *p_sw = (int64_t *)(hd + o_sw), *p_ops = (int64_t *)(hd + o_ops), *p_sw8 = (int64_t *)(hd + up_bytes);
+	int32_t *p_slen = (int32_t *)(hd + o_slen);
+	const bool force8 = !scores_fit_byte(h, mode);    /* large scores: byte-compare kernels */
 	int64_t nwords2 = 0, nwords8 = 0, blob_bytes = 0;
 	for (int64_t k = 0; k < npairs; ++k) {
 		const int a1 = len1[k], a2 = len2[k];
 		p_soff[2 * k] = off1[k] - blob_lo; p_soff[2 * k + 1] = off2[k] - blob_lo;
 		p_slen[2 * k] = a1; p_slen[2 * k + 1] = a2;
-		p_l1[k] = a1; p_l2[k] = a2;
-		p_sw2[2 * k] = p_w12[k] = nwords2; nwords2 += (a1 + 15) / 16 + 1;
-		p_sw2[2 * k + 1] = p_w22[k] = nwords2; nwords2 += (a2 + 15) / 16 + 1;
-		p_sw8[2 * k] = p_w18[k] = nwords8; nwords8 += (a1 + 3) / 4 + 1;
-		p_sw8[2 * k + 1] = p_w28[k] = nwords8; nwords8 += (a2 + 3) / 4 + 1;
+		p_sw[2 * k] = nwords2; nwords2 += (a1 + 15) / 16 + 1;
+		p_sw[2 * k + 1] = nwords2; nwords2 += (a2 + 15) / 16 + 1;
+		p_sw8[2 * k] = nwords8; nwords8 += (a1 + 3) / 4 + 1;
+		p_sw8[2 * k + 1] = nwords8; nwords8 += (a2 + 3) / 4 + 1;
 		blob_bytes = std::max<int64_t>(blob_bytes, std::max(p_soff[2 * k] + a1, p_soff[2 * k + 1] + a2));
 		if (tb) p_ops[k] = ops_off[k] - ops_lo;
 	}
-	const bool force8 = !scores_fit_byte(h, mode);    /* large scores: byte-compare kernels */
+	if (force8) memcpy(p_sw, p_sw8, 2 * n * 8);
 	const int64_t nwords_max = std::max(nwords2, nwords8) + 4;
 	/* device input block: words | descriptor block | flag | raw blob */
 	const size_t b_words = al((size_t)nwords_max * 4), b_blob = al((size_t)blob_bytes + 16);
@@ -1031,57 +1008,62 @@ static int align_host(at_handle *h, int mode, int64_t npairs, const uint8_t *seq
 	if (rc) return rc;
 	char *din = (char *)h->d_in, *dd = din + b_words;
 	uint32_t *d_words = (uint32_t *)din;
-	int64_t *d_soff = (int64_t *)(dd + o_soff), *d_opsoff = (int64_t *)(dd + o_ops);
+	int64_t *d_soff = (int64_t *)(dd + o_soff), *d_swoff = (int64_t *)(dd + o_sw), *d_opsoff = (int64_t *)(dd + o_ops);
+	int64_t *d_woff1 = (int64_t *)(dd + o_w1), *d_woff2 = (int64_t *)(dd + o_w2);
 	int32_t *d_slen = (int32_t *)(dd + o_slen), *d_len1 = (int32_t *)(dd + o_l1), *d_len2 = (int32_t *)(dd + o_l2);
 	int *d_flag = (int *)(dd + desc_bytes);
 	uint8_t *d_blob = (uint8_t *)(dd + desc_bytes + 256);
 	hipStream_t s = h->stream;
-	rc = grow_pinned(h, &h->hp_blob, &h->hp_blob_bytes, (size_t)blob_bytes + 64);
-	if (rc) return rc;
-	if (gate) {
-		/* stage everything, wait for this chunk's turn, queue the copies behind the previous chunk's */
-		memcpy(h->hp_blob, seq_blob + blob_lo, (size_t)blob_bytes);
-		htrace("chunk: staged, pair", pair_base);
-		{
-			std::unique_lock<std::mutex> lk(gate->mu);
-			gate->cv.wait(lk, [&] { return gate->next >= gate_index; });
-		}
-		if (gate_index > 0) HIP_TRY(h, hipStreamWaitEvent(s, gate->done[gate_index - 1], 0));
-		HIP_TRY(h, hipMemcpyAsync(dd, hd, desc_bytes, hipMemcpyHostToDevice, s));
-		HIP_TRY(h, hipMemcpyAsync(d_blob, h->hp_blob, (size_t)blob_bytes, hipMemcpyHostToDevice, s));
-		HIP_TRY(h, hipEventRecord(gate->done[gate_index], s));
-		turn.pass();
-	} else {
-		HIP_TRY(h, hipMemcpyAsync(dd, hd, desc_bytes, hipMemcpyHostToDevice, s));
-		const size_t piece = (size_t)env_ll("AT_HOST_STAGE_PIECE", 1 << 20);
-		for (size_t at = 0; at < (size_t)blob_bytes; at += piece) {   /* (one chunk: the staging of a piece beside the transfer of the one before) */
+	/* a caller whose sequences already lie in page-locked memory (hipHostMalloc / hipHostRegister) is copied from in place */
+	bool caller_pinned = false;
+	{
+		hipPointerAttribute_t pattr;
+		if (hipPointerGetAttributes(&pattr, seq_blob + blob_lo) == hipSuccess) caller_pinned = pattr.type == hipMemoryTypeHost;
+		else (void)hipGetLastError();                  /* (ordinary memory: not an error) */
+		if (env_ll("AT_HOST_NO_PINNED_CALLER", 0)) caller_pinned = false;
+	}
+	const uint8_t *up_src = seq_blob + blob_lo;
+	if (!caller_pinned) {
+		rc = grow_pinned(h, &h->hp_blob, &h->hp_blob_bytes, (size_t)blob_bytes + 64);
+		if (rc) return rc;
+	}
+	/* (Tried and dropped: the chunks of a batch uploading in order -- own streams chained by events, or one copy stream with the
+	 * threads waiting on the host for their own copies -- so that each crosses the link at its full rate and the first sweep
+	 * starts early: 2.28 / 2.37 ms per 100k pairs of C2 against 2.17 side by side, all within the noise of the box.) */
+	HIP_TRY(h, hipMemcpyAsync(dd, hd, up_bytes, hipMemcpyHostToDevice, s));
+	if (caller_pinned) HIP_TRY(h, hipMemcpyAsync(d_blob, up_src, (size_t)blob_bytes, hipMemcpyHostToDevice, s));
+	else {
+		/* pieces of 4 MB: the staging of one beside the transfer of the one before (copies of 1 MB cross the link at 32 GB/s,
+		 * of 5 MB at 50: tools/pcie_rate.py) */
+		const size_t piece = (size_t)env_ll("AT_HOST_STAGE_PIECE", 4 << 20);
+		for (size_t at = 0; at < (size_t)blob_bytes; at += piece) {
 			const size_t nb = std::min(piece, (size_t)blob_bytes - at);
-			memcpy((char *)h->hp_blob + at, seq_blob + blob_lo + at, nb);
+			memcpy((char *)h->hp_blob + at, up_src + at, nb);
 			HIP_TRY(h, hipMemcpyAsync(d_blob + at, (char *)h->hp_blob + at, nb, hipMemcpyHostToDevice, s));
 		}
 	}
 	at::PackArgs pa;
 	pa.nseq = 2 * npairs; pa.blob = d_blob; pa.off = (const long long *)d_soff; pa.len = d_slen;
-	pa.words = d_words; pa.not_acgt = d_flag;
+	pa.woff = (const long long *)d_swoff; pa.words = d_words; pa.not_acgt = d_flag;
 	const unsigned pgrid = (unsigned)std::min<int64_t>((2 * npairs + 3) / 4, 8LL * h->ncu);
 	int bits = force8 ? 8 : 2;
 	int *p_flag = (int *)((char *)h->hp_flag);
 	if (bits == 2) {
 		HIP_TRY(h, hipMemsetAsync(d_flag, 0, 4, s));
-		pa.woff = (const long long *)(dd + o_sw2);
 		hipLaunchKernelGGL(at::at_pack<2>, dim3(pgrid), dim3(256), 0, s, pa);
 		HIP_TRY(h, hipMemcpyAsync(p_flag, d_flag, 4, hipMemcpyDeviceToHost, s));
 		htrace("chunk: uploads and packing queued, pair", pair_base);
 		HIP_TRY(h, hipStreamSynchronize(s));
 		htrace("chunk: packed, pair", pair_base);
-		if (*p_flag) bits = 8;                         /* some byte is not one of ACGT: byte kernels */
+		if (*p_flag) {                                 /* some byte is not one of ACGT: byte words, byte kernels */
+			bits = 8;
+			HIP_TRY(h, hipMemcpyAsync(d_swoff, p_sw8, 2 * n * 8, hipMemcpyHostToDevice, s));
+		}
 	}
-	if (bits == 8) {
-		pa.woff = (const long long *)(dd + o_sw8);
-		hipLaunchKernelGGL(at::at_pack<8>, dim3(pgrid), dim3(256), 0, s, pa);
-	}
+	if (bits == 8) hipLaunchKernelGGL(at::at_pack<8>, dim3(pgrid), dim3(256), 0, s, pa);
+	hipLaunchKernelGGL(at::at_split_desc, dim3((unsigned)std::min<int64_t>((npairs + 255) / 256, 8LL * h->ncu)), dim3(256), 0, s,
+	                   (const long long *)d_swoff, (const int *)d_slen, (long long)npairs, (long long *)d_woff1, (long long *)d_woff2, d_len1, d_len2);
 	HIP_TRY(h, hipGetLastError());
-	int64_t *d_woff1 = (int64_t *)(dd + (bits == 2 ? o_w12 : o_w18)), *d_woff2 = (int64_t *)(dd + (bits == 2 ? o_w22 : o_w28));
 	const size_t b_len1 = al((size_t)npairs * 4);
 	/* device output block: score | end_i | end_j | state | nops | ops */
 	const size_t b_ops = al((size_t)ops_total + 64), b_pfx = al((size_t)(npairs + 1) * 8);
@@ -1328,8 +1310,8 @@ static int align_host_mt(at_handle *h, int mode, int64_t npairs, const uint8_t *
 	htrace("batch: enter, pairs", npairs);
 	bool same = len1 && len2;
 	for (int64_t k = 1; same && k < npairs; ++k) same = len1[k] == len1[0] && len2[k] == len2[0];
-	const long long want = env_ll("AT_HOST_CHUNKS", same ? 8 : 3);
-	const long long min_pairs = env_ll("AT_HOST_CHUNK_MIN", same ? 8192 : 16384);
+	const long long want = env_ll("AT_HOST_CHUNKS", same ? 6 : 3);
+	const long long min_pairs = env_ll("AT_HOST_CHUNK_MIN", 16384);
 	int nchunks = (int)std::max<long long>(1, std::min<long long>(want, 12));
 	if (!h || npairs < 2 * min_pairs || !seq_blob || !off1 || !len1 || !off2 || !len2 || !out_score) nchunks = 1;
 	else nchunks = (int)std::min<long long>(nchunks, npairs / min_pairs);
@@ -1354,15 +1336,6 @@ static int align_host_mt(at_handle *h, int mode, int64_t npairs, const uint8_t *
 	std::vector<int> rcs((size_t)nchunks, AT_OK);
 	std::vector<std::thread> th;
 	const int64_t per = ((npairs + nchunks - 1) / nchunks + 7) & ~(int64_t)7;
-	UploadGate gate;
-	const bool ordered = env_ll("AT_HOST_ORDERED_UPLOADS", 1) != 0;
-	if (ordered) {
-		HIP_TRY(h, hipSetDevice(h->device));
-		for (int c = 0; c < nchunks; ++c) {
-			if (!h->ev_upload[c]) HIP_TRY(h, hipEventCreateWithFlags(&h->ev_upload[c], hipEventDisableTiming));
-			gate.done[c] = h->ev_upload[c];
-		}
-	}
 	auto run = [&](int c) {
 		const int64_t lo = std::min<int64_t>(npairs, c * per), n = std::min<int64_t>(npairs, lo + per) - lo;
 		at_handle *hh = c == 0 ? h : h->kids[(size_t)c - 1];
@@ -1370,7 +1343,7 @@ static int align_host_mt(at_handle *h, int mode, int64_t npairs, const uint8_t *
 		rcs[(size_t)c] = align_host(hh, mode, n, seq_blob, off1 + lo, len1 + lo, off2 + lo, len2 + lo, want_traceback,
 		                            out_score + lo, out_end_i ? out_end_i + lo : nullptr, out_end_j ? out_end_j + lo : nullptr,
 		                            out_state ? out_state + lo : nullptr, out_ops, ops_off ? ops_off + lo : nullptr,
-		                            out_nops ? out_nops + lo : nullptr, out_r1, out_r2, lo, ordered ? &gate : nullptr, c);
+		                            out_nops ? out_nops + lo : nullptr, out_r1, out_r2, lo);
 	};
 	for (int c = 1; c < nchunks; ++c) th.emplace_back(run, c);
 	run(0);

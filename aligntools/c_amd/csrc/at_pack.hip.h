@@ -60,6 +60,17 @@ __global__ __launch_bounds__(256) void at_pack(const PackArgs a)
 	}
 }
 
+/* per-sequence word offsets / lengths (s1 of pair k at 2k, s2 at 2k + 1) -> the per-pair arrays the sweep kernels take.  The host
+ * uploads the interleaved form once; this saves it from uploading the same numbers a second time */
+__global__ __launch_bounds__(256) void at_split_desc(const long long *swoff, const int *slen, long long n,
+                                                     long long *woff1, long long *woff2, int *len1, int *len2)
+{
+	for (long long k = (long long)blockIdx.x * blockDim.x + threadIdx.x; k < n; k += (long long)gridDim.x * blockDim.x) {
+		woff1[k] = swoff[2 * k]; woff2[k] = swoff[2 * k + 1];
+		len1[k] = slen[2 * k]; len2[k] = slen[2 * k + 1];
+	}
+}
+
 /* *flag (preset to 1) becomes 0 unless every pair has exactly the lengths (l1, l2) */
 __global__ __launch_bounds__(256) void at_check_uniform(const int *len1, const int *len2, long long n, int l1, int l2, int *flag)
 {

@@ -306,10 +306,18 @@ AT_DEV long long sweep16_items(const Sweep16Args &a, long long wnext, const long
 		 * row l1, the COMMON l1 of the item's alignments -- the host puts reads of equal length together. */
 		int il1 = l1, il2 = l2;
 		long long pout = 0;                            /* lanes 0 .. 2*NG-1: where the results of alignment `lane` go */
+		bool filler = false;                           /* RAG: this lane's alignment only fills its work item up (a repeat of a pair another lane owns) */
+		int own_len = l1 + l2;                         /* the ops slot of this lane's alignment holds this many (RAG: the pair's own len1 + len2) */
 		if constexpr (RAG) {
 			const long long pc = wk * 2 * NG + lane < a.npairs ? wk * 2 * NG + lane : last;
-			pout = lane < 2 * NG ? (long long)a.order[pc] : 0;
+			/* the host marks the repeats with which it pads a run of equal l1 to whole work items as ~index: they are swept (their
+			 * lanes cannot idle) but store nothing -- several lanes writing one pair's results at once was correct only because
+			 * the values were equal */
+			const int oraw = lane < 2 * NG ? a.order[pc] : 0;
+			filler = oraw < 0;
+			pout = filler ? (long long)~oraw : (long long)oraw;
 			const int o1 = lane < 2 * NG ? a.len1[pout] : 0, o2l = lane < 2 * NG ? a.len2[pout] : 0;
+			own_len = o1 + o2l;
 			pA = __shfl((int)pout, 2 * grp); pB = __shfl((int)pout, 2 * grp + 1);
 			l1A = __shfl(o1, 2 * grp); l1B = __shfl(o1, 2 * grp + 1);
 			l2A = __shfl(o2l, 2 * grp); l2B = __shfl(o2l, 2 * grp + 1);
@@ -320,7 +328,7 @@ AT_DEV long long sweep16_items(const Sweep16Args &a, long long wnext, const long
 			if constexpr (MODE != K_LOCAL) il1 = __builtin_amdgcn_readfirstlane(o1);
 			const bool bad = lane < 2 * NG && (o1 > l1 || o2l > l2 || o1 < 1 || o2l < 1 || (MODE != K_LOCAL && o1 != il1));
 			if (__any(bad)) {   /* a pair that does not fit the frame, is empty, or (global / fit) breaks the item's common l1 */
-				if (lane < 2 * NG && wk * 2 * NG + lane < a.npairs) {
+				if (lane < 2 * NG && wk * 2 * NG + lane < a.npairs && !filler) {
 					a.score[pout] = INT32_MIN;
 					if (a.nops) a.nops[pout] = -1;
 				}
@@ -844,7 +852,7 @@ AT_DEV long long sweep16_items(const Sweep16Args &a, long long wnext, const long
 		{
 			const int g = lane >> 1, h = lane & 1;
 			const long long pin = (wk * NG + g) * 2 + h;          /* = wk * 2 * NG + lane */
-			const bool mine = lane < 2 * NG && pin < a.npairs;
+			const bool mine = lane < 2 * NG && pin < a.npairs && !filler;
 			const long long p = RAG ? pout : pin;                  /* RAG: the host's order array says which pair this is */
 			if (mine) {
 				int ci = my_ci, cj = my_cj, st = my_st, cnt = 0;
@@ -852,7 +860,7 @@ AT_DEV long long sweep16_items(const Sweep16Args &a, long long wnext, const long
 				if constexpr (TB) {
 					uint8_t *ops = a.ops + a.ops_off[p];
 					const int glane = g * G;
-					int guard = l1 + l2 + 2;
+					int guard = own_len + 2;
 					if (AT_WALK_PRIO) __builtin_amdgcn_s_setprio(AT_WALK_PRIO);
 					if (AT_DIAG_NO_WALK) {
 					} else if (ok && OVL) {
@@ -879,7 +887,7 @@ AT_DEV long long sweep16_items(const Sweep16Args &a, long long wnext, const long
 						constexpr int AHEAD = AT_WALK_AHEAD;
 						while (ci > 0 && (ISFIT || cj > 0)) {     /* (global, trace_back_gla :384-397: until either index is 0, then the padding loops) */
 							if (MODE == K_LOCAL && st == 0) break;              /* HOME :788-791 (the cell that pointed home has been emitted) */
-							if (cj <= 0 || cnt >= l1 + l2) { ok = false; break; }   /* (a walk never has more ops than its slot holds) */
+							if (cj <= 0 || cnt >= own_len) { ok = false; break; }   /* (a walk never has more ops than its slot holds) */
 							/* jump state with the bit plane (:579-583): the walk runs left along its row until the column where J opened from M;
 							 * the plane holds 4 columns of the row per word, so the same four loads -- issued together with those of the walks in
 							 * the other states: one round trip to HBM for all 2 .. 16 walks of the wavefront -- cover up to 16 columns */
@@ -929,7 +937,7 @@ AT_DEV long long sweep16_items(const Sweep16Args &a, long long wnext, const long
 									const int tk = ((cj - 1) + ln0) & 3;
 									cols = (cols << (16 - 4 * AHEAD + 3 - tk)) & 0xffffu;            /* bit 15 = column cj */
 									const int avail = 4 * AHEAD - (3 - tk);
-									const int lim = imin(imin(avail, cj), l1 + l2 - cnt);
+									const int lim = imin(imin(avail, cj), own_len - cnt);
 									const int n = __clz((int)((cols << 16) | 0x8000u));
 									const int steps = n < lim ? n + 1 : lim;
 									if (n < lim) st = 2;
@@ -952,7 +960,7 @@ AT_DEV long long sweep16_items(const Sweep16Args &a, long long wnext, const long
 									else { ok = false; go = false; }
 									if (ok) {
 										ops[cnt++] = (uint8_t)op;
-										go = st == was && ci > 0 && cj > 0 && cnt < l1 + l2;   /* the next prefetched cell is the next cell */
+										go = st == was && ci > 0 && cj > 0 && cnt < own_len;   /* the next prefetched cell is the next cell */
 									}
 								}
 							}

@@ -438,8 +438,11 @@ static int batch_worker(int cmd, opt_t *opt, const batch_flags *bf, const char *
 	h = at_host_handle();
 	rc = at_set_scoring(h, opt->m, opt->u, opt->o, opt->e, opt->j, opt->s == AT_TRUE, opt->sites.pos, (int)opt->sites.size);
 	if (rc == AT_OK && comm) {
+		trace("comm: init, rank", rank);
 		rc = at_comm_init(h, rank, world, comm_dir);
+		trace("comm: communicator up, world", world);
 		if (rc == AT_OK) rc = at_comm_broadcast_scoring(h);      /* rank 0's options are everybody's */
+		trace("comm: scoring broadcast done", rc);
 	}
 	if (rc != AT_OK) die("%s", at_last_error(h));
 	if (bf->all_vs_all) {
@@ -500,13 +503,16 @@ static int batch_worker(int cmd, opt_t *opt, const batch_flags *bf, const char *
 			int64_t *bytes = (int64_t *)at_xmalloc((size_t)world * 8), o = 0, q;
 			int32_t *allscore = (int32_t *)at_xmalloc((size_t)(npairs + 1) * 4);
 			char *allpay = NULL;
+			trace("comm: aligned my share, pairs", hi - lo);
 			rc = at_comm_allgather(h, myscore, (hi - lo) * 4, allscore, npairs * 4, bytes);
+			trace("comm: scores gathered, bytes", npairs * 4);
 			if (rc == AT_OK && tb) {
 				int64_t mine = (int64_t)pay.l, total = 0, *sizes = (int64_t *)at_xmalloc((size_t)world * 8);
 				rc = at_comm_allgather(h, &mine, 8, sizes, (int64_t)world * 8, bytes);          /* how much to expect in all */
 				for (q = 0; rc == AT_OK && q < world; ++q) total += sizes[q];
 				allpay = (char *)at_xmalloc((size_t)total + 1);
 				if (rc == AT_OK) rc = at_comm_allgather(h, pay.s, mine, allpay, total, bytes);
+				trace("comm: strings gathered, bytes", total);
 				free(sizes);
 			}
 			if (rc != AT_OK) die("%s", at_last_error(h));

@@ -25,10 +25,15 @@ def _md5(s):
 def al():
     import os
     import aligntools.c_amd as A
+    before = os.environ.get("AT_PACKED_MIN_ROUNDS")
     os.environ["AT_PACKED_MIN_ROUNDS"] = "0"   # small test batches must still reach the 64-lane packed kernels
     a = A.Aligner()
     yield a
     a.close()
+    if before is None:                          # (the default routing is tests/test_default_routing.py's subject)
+        os.environ.pop("AT_PACKED_MIN_ROUNDS", None)
+    else:
+        os.environ["AT_PACKED_MIN_ROUNDS"] = before
 
 
 def _group(cases):

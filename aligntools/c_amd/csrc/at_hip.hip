@@ -1058,7 +1058,7 @@ static int align_host(at_handle *h, int mode, int64_t npairs, const uint8_t *seq
 	if (force8) memcpy(p_sw, p_sw8, 2 * n * 8);
 	const int64_t nwords_max = std::max(nwords2, nwords8) + 4;
 	/* device input block: words | descriptor block | flag | raw blob */
-	const size_t b_words = al((size_t)nwords_max * 4), b_blob = al((size_t)blob_bytes + 16);
+	const size_t b_words = al((size_t)nwords_max * 4), b_blob = al((size_t)blob_bytes + 32);   /* (at_pack reads whole dwords: up to 20 bytes behind the last base) */
 	rc = grow(h, &h->d_in, &h->in_bytes, b_words + desc_bytes + 256 + b_blob);
 	if (rc) return rc;
 	char *din = (char *)h->d_in, *dd = din + b_words;
@@ -1100,7 +1100,7 @@ static int align_host(at_handle *h, int mode, int64_t npairs, const uint8_t *seq
 	at::PackArgs pa;
 	pa.nseq = 2 * npairs; pa.blob = d_blob; pa.off = (const long long *)d_soff; pa.len = d_slen;
 	pa.woff = (const long long *)d_swoff; pa.words = d_words; pa.not_acgt = d_flag;
-	const unsigned pgrid = (unsigned)std::min<int64_t>((2 * npairs + 3) / 4, 8LL * h->ncu);
+	const unsigned pgrid = (unsigned)std::min<int64_t>((2 * npairs + 15) / 16, 8LL * h->ncu);
 	int bits = force8 ? 8 : 2;
 	int *p_flag = (int *)((char *)h->hp_flag);
 	if (bits == 2) {
@@ -1447,7 +1447,7 @@ static int upload_reads(at_handle *h, int mode, int64_t nreads, const uint8_t *s
 	HIP_TRY(h, hipSetDevice(h->device));
 	auto al = [](size_t x) { return (x + 255) & ~(size_t)255; };
 	const size_t b_words = al((size_t)(std::max(nwords2, nwords8) + 4) * 4), b_off = al((size_t)nreads * 8), b_len = al((size_t)nreads * 4);
-	const size_t b_blob = al((size_t)blob_bytes + 16);
+	const size_t b_blob = al((size_t)blob_bytes + 32);   /* (at_pack reads whole dwords: up to 20 bytes behind the last base) */
 	int rc = grow(h, &h->d_in, &h->in_bytes, b_words + 2 * b_off + b_len + 256 + b_blob);
 	if (rc) return rc;
 	char *din = (char *)h->d_in;
@@ -1463,7 +1463,7 @@ static int upload_reads(at_handle *h, int mode, int64_t nreads, const uint8_t *s
 	at::PackArgs pa;
 	pa.nseq = nreads; pa.blob = d_blob; pa.off = (const long long *)d_soff; pa.len = d_len;
 	pa.woff = (const long long *)d_swoff; pa.words = d_words; pa.not_acgt = d_flag;
-	const unsigned pgrid = (unsigned)std::min<int64_t>((nreads + 3) / 4, 8LL * h->ncu);
+	const unsigned pgrid = (unsigned)std::min<int64_t>((nreads + 15) / 16, 8LL * h->ncu);
 	int bits = scores_fit_byte(h, mode) ? 2 : 8, flag = 0;
 	if (bits == 2) {
 		HIP_TRY(h, hipMemsetAsync(d_flag, 0, 4, s));

@@ -163,9 +163,9 @@ def launch_ranks(n, backend):
     """Start `python -m torch.distributed.run --nnodes=1 --nproc-per-node n ... bench.py <same arguments>` as a child process (never
     an exec), pass its stderr through, relay the one JSON line rank 0 prints, return its exit code."""
     import socket
-    try:   # (counting devices initialises nothing on the GPU)
-        import torch
-        have = torch.cuda.device_count()
+    try:   # the devices are counted by a short-lived child: the launcher itself never opens the GPU (a box may cap the processes per card)
+        r = subprocess.run([sys.executable, "-c", "import torch; print(torch.cuda.device_count())"], capture_output=True, text=True, timeout=300)
+        have = int(r.stdout.strip().splitlines()[-1])
     except Exception:
         have = 0
     if backend == "nccl" and have < n and not os.environ.get("BENCH_LAUNCH_DRYRUN"):

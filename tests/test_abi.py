@@ -27,6 +27,20 @@ def test_header_symbols_exported(lib):
         assert getattr(lib, name) is not None
 
 
+def test_reference_named_surface_exported(lib):
+    """libaligntools.so exports every function include/aligntools.h declares -- the five kernels, init_opt / die / kstring_*, the batch
+    reader, and the traceback half: at_fill_matrix, the four trace_back_*() and destory_matrix (alignment.h:372, 558, 766, 896, 153)."""
+    hdr = open(os.path.join(ROOT, "include", "aligntools.h")).read()
+    hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
+    declared = sorted(set(re.findall(r"\b([a-z_]+[a-z0-9_]*)\s*\([^;{]*\)\s*;", hdr)))
+    for need in ("align_gla", "align_local_affine", "align_fit_affine_jump", "align_overlap", "edit_dist", "trace_back_gla", "trace_back_local_affine",
+                 "trace_back_fit_affine_jump", "trace_back_overlap", "destory_matrix", "at_fill_matrix", "init_opt", "die", "kstring_read", "kstring_destory"):
+        assert need in declared, (need, declared)
+    host = C.CDLL(os.path.join(ROOT, "aligntools", "c_amd", "libaligntools.so"))
+    for name in declared:
+        assert getattr(host, name) is not None, name
+
+
 def _no_gpu():
     try:
         import torch

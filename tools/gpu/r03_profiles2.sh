@@ -11,6 +11,26 @@ python3 -c "import __graft_entry__ as g; g.smoke()" > $O/smoke.log 2>&1 && tail 
 timeout -k 10 600 python3 bench.py --workload C4full --steps 5 --warmup 1 >> $O/full_size_bench.jsonl 2>> $O/bench.err
 timeout -k 10 900 python3 bench.py --workload C5full --steps 1 --warmup 0 --streams 1 >> $O/full_size_bench.jsonl 2>> $O/bench.err
 cut -c1-300 $O/full_size_bench.jsonl
+# the C host's own collectives (at_comm_*: RCCL through dlopen) timed at a world of one -- init, the scoring broadcast, the gathers of
+# 100k pairs' scores and strings -- next to the stages of the run (AT_CLI_TRACE)
+python3 - <<'PY' > $O/cli_comm_trace.txt 2>&1
+import os, subprocess, sys, tempfile
+sys.path.insert(0, os.getcwd())
+from aligntools.c_amd.synth import synth_pairs_blob
+EXE = os.path.join("aligntools", "c_amd", "bin", "alignTools")
+n, l1, l2 = 100000, 150, 150
+blob = synth_pairs_blob(0x5EED0002, n, l1, l2)
+with tempfile.TemporaryDirectory() as d:
+    plain = os.path.join(d, "pairs.fa")
+    with open(plain, "wb") as fh:
+        for k, row in enumerate(blob):
+            fh.write(b">a%d\n" % k + row[:l1].tobytes() + b"\n>b%d\n" % k + row[l1:].tobytes() + b"\n")
+    for env in (dict(os.environ, AT_CLI_TRACE="1", AT_COMM_FORCE_RCCL="1", HSA_ENABLE_IPC_MODE_LEGACY="0"), dict(os.environ, AT_CLI_TRACE="1")):
+        p = subprocess.run([EXE, "batch", "local", "-m", "2", "-u", "-2", "-o", "-5", "-e", "-2", plain], stdout=subprocess.DEVNULL, stderr=subprocess.PIPE, env=env)
+        print("rc", p.returncode, "RCCL world of one" if "AT_COMM_FORCE_RCCL" in env else "no communicator (streaming pipeline)")
+        print(p.stderr.decode())
+PY
+cat $O/cli_comm_trace.txt | cut -c1-120
 : > $O/fuzz_parity.txt
 for seed in 3101 3102 3103 3104 3105 3106; do
   timeout -k 10 900 python3 tests/fuzz_parity.py 60000 $seed >> $O/fuzz_parity.txt 2>&1 || { tail -30 $O/fuzz_parity.txt; exit 1; }

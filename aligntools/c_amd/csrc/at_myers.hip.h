@@ -9,7 +9,9 @@
  * default, is not a distance and has no such encoding.
  *
  * Mapping: G lanes per alignment (G = 32: two alignments per wavefront, l1 <= 1024 * W; G = 8: eight alignments of
- * reads up to 256 bases; each alignment with its own lengths), W consecutive words (32*W rows) per lane, the words of
+ * reads up to 256 bases; G = 1 (round 3): ONE ALIGNMENT PER LANE, 64 per wavefront, W = 5 or 8 words for reads of up to 160 / 256
+ * bases -- no skew, no idle lanes, a column step of W chained word steps per lane: 230 instead of 965 instructions per alignment
+ * of 150 x 150; each alignment with its own lengths), W consecutive words (32*W rows) per lane, the words of
  * a column chained through the horizontal difference (hin/hout).
  * Like the sweep kernels the lanes are skewed: lane l works on column t - l at step t and takes the
  * horizontal difference of the word above from lane l-1's previous step by one DPP move.  The first word's
@@ -47,7 +49,7 @@ AT_DEV uint32_t eq16(uint32_t w, uint32_t c)
 template <int W, int G>
 __global__ __launch_bounds__(64) void at_myers(const MyersArgs a)
 {
-	static_assert(G == 32 || G == 8, "lanes per alignment");
+	static_assert(G == 32 || G == 8 || G == 1, "lanes per alignment");
 	constexpr int NG = 64 / G;                         /* alignments per wavefront */
 	const int lane = threadIdx.x;
 	const int grp = lane / G, lg = lane % G;

@@ -20,6 +20,8 @@ def draw_batch(rng):
     only = os.environ.get("AT_FUZZ_MODES")          # e.g. "fitj,overlap": a campaign aimed at those kernels
     mode = rng.choice(only.split(",") if only else ["global", "local", "fit", "fit", "overlap", "edit"])
     sc = rng.choice(SCORINGS)
+    if mode == "edit" and os.environ.get("AT_FUZZ_EDIT_UNIT"):   # unit mismatch cost: the bit-parallel kernel on DNA (no extra draw: the seeds keep their streams)
+        sc = (sc[0], 1) + sc[2:]
     alpha = rng.choice(ALPHABETS)
     uj = (mode == "fit" and rng.random() < 0.5) or mode == "fitj"
     mode = "fit" if mode == "fitj" else mode
@@ -71,7 +73,8 @@ def kernel_class(cfg):
     "int32", "myers" -- what a campaign has covered."""
     import re
     if "myers" in cfg:
-        return "myers"
+        m = re.search(r"words/lane=(\d+) (\d+)x(\d+)-lane", cfg)
+        return "myers W%s %sx%s" % m.groups() if m else "myers"
     m = re.search(r"packed16 x(\d+) bits=(\d) (\d+)x(\d+)-lane groups.*?rows/lane=(\d+)", cfg)
     if not m:
         return "int32"

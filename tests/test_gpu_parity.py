@@ -1098,12 +1098,39 @@ def test_bit_parallel_edit_distance(al):
     assert "myers" in al.last_config and "words/lane=8" in al.last_config, al.last_config
     for k, (a, b) in enumerate(ragged):
         assert int(res["score"][k]) == O.align(O.EDIT, a, b, 1, 1, -5, -1)["score"], (k, len(a), len(b))
-    for l1, l2, want in ((150, 150, 1), (1000, 1000, 1), (1024, 700, 1), (1025, 1100, 2), (33, 2000, 1)):
-        uniform = [(dna(l1), dna(l2)) if k % 2 else (lambda a: (a, (related(a) + dna(l2))[:l2]))(dna(l1)) for k in range(70)]
+    # reads of up to 256 bases: one alignment per LANE (64 per wavefront), 5 words for up to 160 bases, 8 beyond; a second sequence too
+    # long for 64 windows in LDS keeps the eight-lane groups
+    for l1, l2, want, groups in ((150, 150, 5, "64x1-lane"), (160, 90, 5, "64x1-lane"), (161, 300, 8, "64x1-lane"), (256, 256, 8, "64x1-lane"),
+                                 (33, 2000, 5, "64x1-lane"), (40, 4000, 1, "8x8-lane"), (1000, 1000, 1, "2x32-lane"), (1024, 700, 1, "2x32-lane"),
+                                 (1025, 1100, 2, "2x32-lane")):
+        uniform = [(dna(l1), dna(l2)) if k % 2 else (lambda a: (a, (related(a) + dna(l2))[:l2]))(dna(l1)) for k in range(70 if l1 > 256 else 200)]
         res = al.align_batch("edit", uniform)
-        assert "words/lane=%d" % want in al.last_config, al.last_config
+        assert "words/lane=%d" % want in al.last_config and groups in al.last_config, al.last_config
         for k, (a, b) in enumerate(uniform):
             assert int(res["score"][k]) == O.align(O.EDIT, a, b, 1, 1, -5, -1)["score"], (l1, l2, k)
+    # ragged short reads, every length 1 .. 256 with every word boundary, one alignment per lane each with its own lengths
+    short = [(dna(n), related(dna(n)) if n % 3 else dna(rng.randint(1, 300))) for n in range(1, 257)] + [("", "ACGT"), ("ACG", "")]
+    res = al.align_batch("edit", short)
+    assert "64x1-lane" in al.last_config and "words/lane=8" in al.last_config, al.last_config
+    for k, (a, b) in enumerate(short):
+        assert int(res["score"][k]) == O.align(O.EDIT, a, b, 1, 1, -5, -1)["score"], (k, len(a), len(b))
+    # reads of 257 .. 1 024 bases: one alignment per lane as well (16 / 32 words) once the batch has a wavefront per CU -- here forced
+    os.environ["AT_MYERS_LANE_MIN_PAIRS"] = "1"
+    try:
+        for l1, l2, want in ((257, 300, 16), (300, 300, 16), (512, 200, 16), (513, 600, 32), (1000, 1000, 32), (1024, 700, 32)):
+            uniform = [(dna(l1), dna(l2)) if k % 2 else (lambda a: (a, (related(a) + dna(l2))[:l2]))(dna(l1)) for k in range(70)]
+            res = al.align_batch("edit", uniform)
+            assert "words/lane=%d" % want in al.last_config and "64x1-lane" in al.last_config, al.last_config
+            for k, (a, b) in enumerate(uniform):
+                assert int(res["score"][k]) == O.align(O.EDIT, a, b, 1, 1, -5, -1)["score"], (l1, l2, k)
+        longer = [(dna(n), related(dna(n)) if n % 3 else dna(rng.randint(1, 1200))) for n in list(range(250, 1025, 7)) + [511, 512, 513, 991, 992, 993, 1023, 1024]]
+        longer += [("", "ACGT"), ("ACG", ""), (dna(1024), dna(1))]
+        res = al.align_batch("edit", longer)
+        assert "64x1-lane" in al.last_config and "words/lane=32" in al.last_config, al.last_config
+        for k, (a, b) in enumerate(longer):
+            assert int(res["score"][k]) == O.align(O.EDIT, a, b, 1, 1, -5, -1)["score"], (k, len(a), len(b))
+    finally:
+        del os.environ["AT_MYERS_LANE_MIN_PAIRS"]
     al.set_scoring(1, 2, -5, -1)          # another mismatch cost: the DP kernel
     res = al.align_batch("edit", ragged[:20])
     assert "int32" in al.last_config

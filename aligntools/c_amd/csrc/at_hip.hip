@@ -909,7 +909,7 @@ static int align_device(at_handle *h, int mode, int64_t npairs,
 		 * SIMDs, 19 TCUPS against 31 on 32-lane groups; 131 072 of them 43 against 36.  AT_MYERS_GROUP = 8: the round-2 form, eight lanes
 		 * for reads of up to 256 bases and 32 beyond (A/B) */
 		const long long lane_max = env_ll("AT_MYERS_LANE_MAX", 1024);
-		const bool per_lane = max_len1 <= lane_max && max_len1 <= 1024 && (size_t)64 * (((size_t)max_len2 + 15) / 16 + 2) * 4 <= 60 * 1024 &&
+		const bool per_lane = max_len1 <= lane_max && max_len1 <= 1024 && (size_t)64 * ((((size_t)max_len2 + 15) / 16 + 2) | 1) * 4 <= 60 * 1024 &&
 		                      (max_len1 <= 256 || npairs >= env_ll("AT_MYERS_LANE_MIN_PAIRS", 16384)) && env_ll("AT_MYERS_GROUP", 1) == 1;
 		const int g = per_lane ? 1 : max_len1 <= 256 ? 8 : 32;
 		const int w = per_lane ? (max_len1 <= 160 ? 5 : max_len1 <= 256 ? 8 : max_len1 <= 512 ? 16 : 32)
@@ -926,7 +926,7 @@ static int align_device(at_handle *h, int mode, int64_t npairs,
 		if (!h->d_queue) HIP_TRY(h, hipMalloc((void **)&h->d_queue, 64));
 		HIP_TRY(h, hipMemsetAsync(h->d_queue, 0, 8, stream));
 		m.queue = h->d_queue;
-		const size_t lds = (size_t)per_wave * (((size_t)max_len2 + 15) / 16 + 2) * 4;
+		const size_t lds = (size_t)per_wave * ((((size_t)max_len2 + 15) / 16 + 2) | 1) * 4;   /* (odd window stride, as the kernel computes it) */
 		if (lds > 60 * 1024) return fail(h, AT_ERR_RANGE, "second sequence too long for the bit-parallel kernel's LDS window");
 		int occ = 0;
 		if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, (const void *)fn, 64, lds) != hipSuccess || occ <= 0) occ = 8;

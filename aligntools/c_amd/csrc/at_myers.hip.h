@@ -34,18 +34,28 @@ struct MyersArgs {
 	unsigned long long *queue;
 };
 
-/* bit k of the result = (2-bit code k of `w` == c), k = 0..15 */
-AT_DEV uint32_t eq16(uint32_t w, uint32_t c)
+/* bit k of the result = bit 2k of `w`, k = 0..15 (one bit plane of sixteen 2-bit codes) */
+AT_DEV uint32_t even16(uint32_t w)
 {
-	const uint32_t v = w ^ (c * 0x55555555u);
-	uint32_t m = ~(v | (v >> 1)) & 0x55555555u;      /* even bits: code equal */
+	uint32_t m = w & 0x55555555u;
 	m = (m | (m >> 1)) & 0x33333333u;
 	m = (m | (m >> 2)) & 0x0f0f0f0fu;
 	m = (m | (m >> 4)) & 0x00ff00ffu;
 	m = (m | (m >> 8)) & 0x0000ffffu;
 	return m;
 }
-
+/* One column step of one word costs 14 instructions (round 2: 27):
+ *   - s1 is kept as two bit planes (B0 / B1 = low / high bit of the code of each row) instead of four match masks: Eq = (B0 ^ ~C0) & (B1 ^ ~C1)
+ *     with the column's code spread to two all-ones / all-zeros words once per column -- three instructions like the selects before, half
+ *     the registers (the 32-word form: 128 instead of 192 + 64);
+ *   - the boolean forms are written plainly: gfx950's v_bitop3_b32 takes any function of three words, and hipcc finds them
+ *     (Mv | ~(sum | Pv | Eq) in two, Mhs | ~(Xv | Phs) and Phs & (Eq | Mv) in one each);
+ *   - the shifted horizontal differences are one v_alignbit each over (this word, the word above): no carry bits are extracted;
+ *   - nothing is accumulated per step: when a lane has passed its last column its Pv / Mv ARE the vertical differences of column l2, and
+ *     D(l1, l2) = D(0, l2) + sum over rows <= l1 = l2 + popcount(Pv & rows) - popcount(Mv & rows), summed over the words and lanes of
+ *     the alignment once, at the end.
+ * Rows behind l1 hold code 0 and may match: differences only ever travel towards higher rows (the add's carry, the shifts), so they never
+ * reach a row <= l1, and the final count masks them. */
 template <int W, int G>
 __global__ __launch_bounds__(64) void at_myers(const MyersArgs a)
 {
@@ -53,7 +63,7 @@ __global__ __launch_bounds__(64) void at_myers(const MyersArgs a)
 	constexpr int NG = 64 / G;                         /* alignments per wavefront */
 	const int lane = threadIdx.x;
 	const int grp = lane / G, lg = lane % G;
-	const int nw2max = ((a.max_l2 + 15) >> 4) + 2;
+	const int nw2max = (((a.max_l2 + 15) >> 4) + 2) | 1;   /* odd: the windows of the 64 lanes start in different LDS banks */
 	uint32_t *ref = at_lds + grp * nw2max;             /* my alignment's s2 words */
 	const long long nwork = (a.npairs + NG - 1) / NG;
 	long long wnext = blockIdx.x;
@@ -69,68 +79,76 @@ __global__ __launch_bounds__(64) void at_myers(const MyersArgs a)
 		/* ---- stage s2 ---- */
 		const int nw2 = fits ? (l2 + 15) >> 4 : 0;
 		for (int w = lg; w < nw2; w += G) ref[w] = r[w];
-		/* ---- my W words of s1: match masks per code, all-ones vertical state ---- */
-		uint32_t P0[W], P1[W], P2[W], P3[W], Pv[W], Mv[W];
+		/* ---- my W words of s1 as two bit planes, all-ones vertical state (D(i,0) = i) ---- */
+		uint32_t B0[W], B1[W], Pv[W], Mv[W];
 		const int nw1 = fits ? (l1 + 15) >> 4 : 0;
 #pragma unroll
 		for (int w = 0; w < W; ++w) {
 			const int b = lg * W + w;                      /* word index: rows 32b+1 .. 32b+32 */
 			const uint32_t lo = 2 * b < nw1 ? q[2 * b] : 0u, hi = 2 * b + 1 < nw1 ? q[2 * b + 1] : 0u;
-			/* rows behind l1 must match nothing (they never feed a lower bit anyway) */
-			const int valid = l1 - 32 * b;                 /* rows of this word inside s1 */
-			const uint32_t vm = valid >= 32 ? 0xffffffffu : valid <= 0 ? 0u : ((1u << valid) - 1u);
-			P0[w] = (eq16(lo, 0) | (eq16(hi, 0) << 16)) & vm;
-			P1[w] = (eq16(lo, 1) | (eq16(hi, 1) << 16)) & vm;
-			P2[w] = (eq16(lo, 2) | (eq16(hi, 2) << 16)) & vm;
-			P3[w] = (eq16(lo, 3) | (eq16(hi, 3) << 16)) & vm;
+			B0[w] = even16(lo) | (even16(hi) << 16);
+			B1[w] = even16(lo >> 1) | (even16(hi >> 1) << 16);
 			Pv[w] = 0xffffffffu; Mv[w] = 0u;
 		}
 		__builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");   /* LDS writes of this wave before its reads */
-		/* the word and bit that hold row l1 */
-		const int ob = l1 > 0 ? (l1 - 1) >> 5 : 0;
-		const int olane = ob / W, oword = ob % W, obit = l1 > 0 ? (l1 - 1) & 31 : 0;
-		const int nlanes = l1 > 0 ? olane + 1 : 0;
-		int acc = 0;                                       /* sum of horizontal differences at row l1 (owner lane) */
-		uint32_t hp_out = 0, hm_out = 0;                   /* horizontal difference leaving my last word (previous step) */
+		const int nlanes = l1 > 0 ? (((l1 - 1) >> 5) / W) + 1 : 0;   /* lanes of the alignment that hold rows <= l1 */
+		uint32_t hp_out = 0, hm_out = 0;                   /* horizontal differences of my last word (previous step), whole words */
 		/* the alignments of the wave step together: the longest one decides the trip count */
 		const int steps_mine = (fits && have && l1 > 0 && l2 > 0) ? l2 + nlanes - 1 : 0;
 		int nsteps = steps_mine;
 #pragma unroll
 		for (int d = 32; d >= 1; d >>= 1) nsteps = imax(nsteps, __shfl_xor(nsteps, d));
+		uint32_t cw = 0;                                   /* (G == 1) the sixteen codes of s2 around column t */
 		for (int t = 0; t < nsteps; ++t) {
-			/* what the word above me (lane - 1's last word) sent out one step ago; lane 0 of an alignment: +1 */
-			uint32_t hp = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)hp_out, 0x138 /* wave_shr:1 */, 0xf, 0xf, false);
-			uint32_t hm = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)hm_out, 0x138, 0xf, 0xf, false);
-			if (lg == 0) { hp = 1u; hm = 0u; }
+			/* the word above my first one: lane - 1's last word one step ago; first lane of an alignment: the border, +1 */
+			uint32_t pP, pM;
+			if constexpr (G == 1) { pP = 0x80000000u; pM = 0u; }
+			else {
+				pP = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)hp_out, 0x138 /* wave_shr:1 */, 0xf, 0xf, false);
+				pM = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)hm_out, 0x138, 0xf, 0xf, false);
+				if (lg == 0) { pP = 0x80000000u; pM = 0u; }
+			}
 			const int j = t - lg;
 			const bool active = lg < nlanes && j >= 0 && j < l2 && t < steps_mine;
+			uint32_t c = 0;
+			if constexpr (G == 1) {                        /* every lane is at column t: one LDS word per sixteen columns */
+				if ((t & 15) == 0) cw = t < l2 ? ref[t >> 4] : 0u;
+				c = cw; cw >>= 2;
+			}
 			if (active) {
-				const uint32_t c = (ref[j >> 4] >> ((j & 15) * 2)) & 3u;
-				const bool c0 = (c & 1u) != 0, c1 = (c & 2u) != 0;
+				if constexpr (G != 1) c = ref[j >> 4] >> ((j & 15) * 2);
+				const uint32_t nC0 = (c & 1u) - 1u, nC1 = ((c >> 1) & 1u) - 1u;   /* ~(bit of the code spread over the word) */
 #pragma unroll
 				for (int w = 0; w < W; ++w) {
-					const uint32_t e01 = c0 ? P1[w] : P0[w], e23 = c0 ? P3[w] : P2[w];
-					uint32_t Eq = c1 ? e23 : e01;
+					const uint32_t Eq = (B0[w] ^ nC0) & (B1[w] ^ nC1);
+					const uint32_t Eqh = Eq | (pM >> 31);      /* hin < 0 */
+					const uint32_t sum = (Eqh & Pv[w]) + Pv[w];
+					const uint32_t Xh = (sum ^ Pv[w]) | Eqh;
+					const uint32_t Ph = Mv[w] | ~(Xh | Pv[w]);
+					const uint32_t Mh = Pv[w] & Xh;
+					const uint32_t Phs = __builtin_amdgcn_alignbit(Ph, pP, 31);   /* (Ph << 1) | hin > 0 */
+					const uint32_t Mhs = __builtin_amdgcn_alignbit(Mh, pM, 31);
 					const uint32_t Xv = Eq | Mv[w];
-					Eq |= hm;                                  /* hin < 0 */
-					const uint32_t Xh = (((Eq & Pv[w]) + Pv[w]) ^ Pv[w]) | Eq;
-					uint32_t Ph = Mv[w] | ~(Xh | Pv[w]);
-					uint32_t Mh = Pv[w] & Xh;
-					if (w == oword && lg == olane) acc += (int)((Ph >> obit) & 1u) - (int)((Mh >> obit) & 1u);
-					const uint32_t ph_o = Ph >> 31, mh_o = Mh >> 31;
-					Ph = (Ph << 1) | hp;
-					Mh = (Mh << 1) | hm;
-					Pv[w] = Mh | ~(Xv | Ph);
-					Mv[w] = Ph & Xv;
-					hp = ph_o; hm = mh_o;
+					Pv[w] = Mhs | ~(Xv | Phs);
+					Mv[w] = Phs & Xv;
+					pP = Ph; pM = Mh;
 				}
-				hp_out = hp; hm_out = hm;
+				hp_out = pP; hm_out = pM;
 			}
 		}
-		/* ---- result ---- */
+		/* ---- result: D(l1, l2) = l2 + the vertical differences of the last column over rows 1 .. l1 ---- */
+		int sum = 0;
+#pragma unroll
+		for (int w = 0; w < W; ++w) {
+			const int valid = l1 - 32 * (lg * W + w);      /* rows of this word inside s1 */
+			const uint32_t vm = valid >= 32 ? 0xffffffffu : valid <= 0 ? 0u : ((1u << valid) - 1u);
+			sum += __popc(Pv[w] & vm) - __popc(Mv[w] & vm);
+		}
+#pragma unroll
+		for (int d = G / 2; d >= 1; d >>= 1) sum += __shfl_xor(sum, d);
 		int d;
 		if (l1 <= 0 || l2 <= 0) d = imax(l1, 0) + imax(l2, 0);   /* border: D(i,0) = i, D(0,j) = j */
-		else d = l1 + __shfl(acc, grp * G + olane);
+		else d = l2 + sum;
 		if (have && lg == 0) {
 			a.score[p] = fits ? d : INT32_MIN;
 			if (a.end_i) a.end_i[p] = l1;

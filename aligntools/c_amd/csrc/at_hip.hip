@@ -373,11 +373,13 @@ static Layout layout_for(int kmode, int bits, bool tb, int max_l1, int max_l2)
 /* The 2-bit kernels read scores from a signed-byte LUT: scaled match/mismatch (minus the gap for overlap) must fit. */
 static bool scores_fit_byte(const at_handle *h, int mode)
 {
-	long long a, b;
-	if (mode == AT_MODE_EDIT) { a = 0; b = h->u; }
-	else if (mode == AT_MODE_OVERLAP) { a = 16LL * (h->m - h->o); b = 16LL * (h->u - h->o); }
-	else { a = 16LL * h->m; b = 16LL * h->u; }
-	return std::llabs(a) <= 127 && std::llabs(b) <= 127;
+	long long a, b, c = 0, d = 0;
+	if (mode == AT_MODE_EDIT) { a = 0; b = h->u; c = (long long)h->u - 2; }   /* (the sweep's table holds cost - 2: at_sweep.hip.h, RAMP) */
+	else if (mode == AT_MODE_OVERLAP) {
+		a = 16LL * (h->m - h->o); b = 16LL * (h->u - h->o);                     /* with pointers: s - o, scaled */
+		c = (long long)h->m - 2LL * h->o; d = (long long)h->u - 2LL * h->o;     /* scores only: s - 2 o, unscaled */
+	} else { a = 16LL * h->m; b = 16LL * h->u; }
+	return std::llabs(a) <= 127 && std::llabs(b) <= 127 && std::llabs(c) <= 127 && std::llabs(d) <= 127;
 }
 
 /* ---- packed int16 path (at_sweep16.hip.h): two same-shape pairs per wave ---- */

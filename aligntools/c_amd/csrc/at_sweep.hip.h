@@ -274,10 +274,25 @@ __global__ __launch_bounds__(64) void at_sweep(const SweepArgs a)
 	pm.g = PTRLDS ? nullptr : a.ws + (long long)blockIdx.x * a.ws_slot_words;
 	const int m16 = a.m16, u16 = a.u16, o16 = a.o16, e16 = a.e16, g16 = a.g16;
 	const int NL = a.ptr_lanes;
+	/* Overlap without pointers and edit distance sweep the matrix MINUS ITS GAP RAMP: with M'(i,j) = M(i,j) - o (i + j),
+	 *   M'(i,j) = max3(M'(i,j-1), M'(i-1,j-1) + s - 2 o, M'(i-1,j))
+	 * -- the two gap candidates lose their additions (every candidate of a cell carries the same offset, so the maximum and its
+	 * first-wins order are what they were), a cell is two instructions (v_add_u32_sdwa, v_max3_i32) instead of three; the true value
+	 * is restored where it is compared across columns (the scan of row l1) and at the end.  Nothing here needs the x16 room of the
+	 * priority tags, so these sweeps run on unscaled scores (s - 2 o must fit the byte table).  Edit distance: D' = D - (i + j),
+	 * both borders become 0, D' = min3(D'(i,j-1), D'(i-1,j-1) + cost - 2, D'(i-1,j)). */
+	constexpr bool RAMP = (MODE == K_OVERLAP && !TB) || MODE == K_EDIT;
+	/* On the ramp a row never lies below the row above it (the RIGHT candidate costs nothing), so the rows a lane holds BEHIND l1 can be
+	 * made exact copies of row l1: their query code selects a score of -128 from the table's second word and their column 0 holds
+	 * row l1's -- LEFT and DIAGONAL then never beat RIGHT.  The scan of row l1 (:951-959) reads the lane's last row, a fixed register,
+	 * instead of picking row (l1 - 1) % K every step (a branch tree of four levels per step: a quarter of the sweep's time on C5). */
+	constexpr bool COPYROWS = MODE == K_OVERLAP && !TB && BITS == 2;
+	const uint32_t lutneg = COPYROWS ? 0x80808080u : 0u;
+	const int o1 = MODE == K_EDIT ? 1 : (o16 >> kShift);   /* the ramp's slope (edit: unit gaps) */
 	/* keep the mismatch score in a VGPR the compiler will not re-materialise per step */
-	int u16v = MODE == K_EDIT ? a.u_raw : (MODE == K_OVERLAP ? u16 - o16 : u16);
+	int u16v = MODE == K_EDIT ? a.u_raw - 2 : (MODE == K_OVERLAP ? (TB ? u16 - o16 : (u16 - 2 * o16) >> kShift) : u16);
 	asm volatile("" : "+v"(u16v));
-	const int m16s = MODE == K_EDIT ? 0 : (MODE == K_OVERLAP ? m16 - o16 : m16);
+	const int m16s = MODE == K_EDIT ? -2 : (MODE == K_OVERLAP ? (TB ? m16 - o16 : (m16 - 2 * o16) >> kShift) : m16);
 	/* signed-byte score LUT {match, mismatch x3} for the 2-bit path (the host guarantees both fit a byte) */
 	uint32_t lut8 = ((uint32_t)m16s & 0xffu) | (((uint32_t)u16v & 0xffu) * 0x01010100u);
 	/* penalties and bit masks in VGPRs: an SGPR operand makes v_add_u32 half-rate on gfx950 (tools/valu_rate.hip) */
@@ -336,9 +351,9 @@ __global__ __launch_bounds__(64) void at_sweep(const SweepArgs a)
 				mem.st2(a.off_bound + 2 * j, (uint32_t)xo_of<MODE, TB>(L, M, U, J),
 				        (uint32_t)imax((L | TgL) + e16, (M | TgM) + o16));
 			} else if constexpr (MODE == K_OVERLAP) {
-				mem.st(a.off_bound + 2 * j, (uint32_t)((j == 0 ? 0 : kNeg) + o16));   /* :937-938 */
+				mem.st(a.off_bound + 2 * j, (uint32_t)((j == 0 ? 0 : kNeg) + (TB ? o16 : 0)));   /* :937-938 */
 			} else {
-				mem.st(a.off_bound + 2 * j, (uint32_t)j);                              /* :302 */
+				mem.st(a.off_bound + 2 * j, 0u);                                       /* D(0,j) = j :302, minus the ramp */
 			}
 		}
 		mem.sync();
@@ -370,6 +385,7 @@ __global__ __launch_bounds__(64) void at_sweep(const SweepArgs a)
 				const int qi = imin(i0 + r, l1 - 1);
 				const uint32_t qw = q_words[qi / BPW];
 				qrep[r] = ((qw >> ((qi % BPW) * BITS)) & BMASK) * 0x01010101u;
+				if constexpr (COPYROWS) qrep[r] = i0 + r >= l1 ? 0x04040404u : qrep[r];   /* selectors 4..7: the -128 word */
 				best_r[r] = INT32_MIN; bt_r[r] = 0; acc[r] = 0;
 				const int i = i0 + r + 1;
 				if constexpr (AFFINE) {
@@ -383,9 +399,9 @@ __global__ __launch_bounds__(64) void at_sweep(const SweepArgs a)
 					Xl[0][r] = xo_of<MODE, TB>(L, M, U, J);
 					Xl[1][r] = Xl[0][r];
 				} else if constexpr (MODE == K_OVERLAP) {
-					Mo_l[r] = o16;           /* M(i,0) = 0 -> P = M + o */
+					Mo_l[r] = TB ? o16 : -o1 * (COPYROWS ? imin(i, l1) : i);   /* M(i,0) = 0 -> P = M + o (with pointers) or M - o i (ramp) */
 				} else {
-					Mo_l[r] = i;             /* D(i,0) = i */
+					Mo_l[r] = 0;             /* D(i,0) = i, minus the ramp */
 				}
 			}
 			/* what the lane below sees as "row above, column 0", and my own diagonal */
@@ -396,9 +412,9 @@ __global__ __launch_bounds__(64) void at_sweep(const SweepArgs a)
 				border<MODE>(base, 0, o16, e16, L, M, U, J);
 				Ad = xo_of<MODE, TB>(L, M, U, J);
 			} else if constexpr (MODE == K_OVERLAP) {
-				A_prev = o16; Ad = o16;
+				A_prev = TB ? o16 : -o1 * (i0 + K); Ad = TB ? o16 : -o1 * i0;
 			} else {
-				A_prev = i0 + K; Ad = base;
+				A_prev = 0; Ad = 0;
 			}
 			/* boundary entries of columns t0+1+lane (lanes 0..7 matter), one block ahead */
 			auto load_bound = [&](int t0, int &bx, int &bl) {
@@ -430,8 +446,8 @@ __global__ __launch_bounds__(64) void at_sweep(const SweepArgs a)
 #pragma unroll
 					for (int r = 0; r < K; ++r) {
 						if constexpr (BITS == 2) {
-							xs[0][r] = __builtin_amdgcn_perm(0u, lut8, lo ^ qrep[r]);
-							xs[1][r] = __builtin_amdgcn_perm(0u, lut8, hi ^ qrep[r]);
+							xs[0][r] = __builtin_amdgcn_perm(lutneg, lut8, lo ^ qrep[r]);
+							xs[1][r] = __builtin_amdgcn_perm(lutneg, lut8, hi ^ qrep[r]);
 						} else {
 							xs[0][r] = lo ^ qrep[r]; xs[1][r] = hi ^ qrep[r];
 						}
@@ -464,7 +480,8 @@ __global__ __launch_bounds__(64) void at_sweep(const SweepArgs a)
 							/* end-cell scan of row l1 over columns 0..l2-1 (:676-690, :954-959), one column
 							 * behind the sweep: the left state still holds column j-1 = jm1 */
 							if (laststrip) {
-								const int vM = pick<K>(Mo_l, rl) - o16;
+								/* (ramp: the true M(l1, jm1) = M' + o (l1 + jm1), scaled like every result) */
+								const int vM = RAMP ? ((COPYROWS ? Mo_l[K - 1] : pick<K>(Mo_l, rl)) + o1 * (l1 + jm1)) << kShift : pick<K>(Mo_l, rl) - o16;
 								if (lane == lastlane && vM > best) { best = vM; best_j = jm1; }
 								if constexpr (AFFINE) {
 									const int vL = pick<K>(L_l, rl);
@@ -524,14 +541,14 @@ __global__ __launch_bounds__(64) void at_sweep(const SweepArgs a)
 									P = (Mraw & ~15) + o16v;
 									nib[r] = (uint32_t)Mraw;
 								} else {
-									/* scores only: the priority tags decide pointers, never values */
-									P = imax3(old, diag + s16, up) + o16v;
+									/* scores only: the priority tags decide pointers, never values; no gap additions on the ramp */
+									P = imax3(old, diag + s16, up);
 								}
 								Mo_l[r] = P; diag = old; up = P;
 							} else {
 								/* min3(D(i,j-1)+1, D(i-1,j-1)+cost, D(i-1,j)+1)  :306-309 */
 								const int old = Mo_l[r];
-								const int D = imin3(old + 1, diag + s16, up + 1);
+								const int D = imin3(old, diag + s16, up);
 								Mo_l[r] = D; diag = old; up = D;
 							}
 						}
@@ -628,7 +645,7 @@ __global__ __launch_bounds__(64) void at_sweep(const SweepArgs a)
 			ok = l2 >= 1;
 		} else {
 			int d;
-			if (l1 >= 1 && l2 >= 1) d = __builtin_amdgcn_readlane(pick<K>(Mo_l, rl), lastlane);
+			if (l1 >= 1 && l2 >= 1) d = __builtin_amdgcn_readlane(pick<K>(Mo_l, rl), lastlane) + l1 + l2;   /* (the ramp back) */
 			else d = l1 + l2;              /* border: D(i,0)=i, D(0,j)=j */
 			sc16 = d << kShift; ci = l1; cj = l2;
 		}

@@ -65,7 +65,10 @@ def draw_batch(rng):
         pairs.append((a, b))
     max_l2 = max(s[1] for s in shapes)
     sites = sorted(rng.sample(range(max_l2 + 3), min(max_l2, rng.choice([0, 1, 3, 8])))) if uj else []
-    return mode, sc, uj, sites, pairs, rng.random() < 0.8
+    tb = rng.random() < 0.8
+    if os.environ.get("AT_FUZZ_TB") in ("0", "1"):          # a campaign of scores-only (0) or traceback (1) batches; the draw above keeps the seeds' streams
+        tb = os.environ["AT_FUZZ_TB"] == "1"
+    return mode, sc, uj, sites, pairs, tb
 
 
 def kernel_class(cfg):
@@ -102,7 +105,8 @@ def run(cases, seed, al=None, verbose=True, classes=None):
             batches += 1
             continue
         if classes is not None:
-            classes[(mode + ("j" if uj else "")) + " " + kernel_class(al.last_config)] = classes.get((mode + ("j" if uj else "")) + " " + kernel_class(al.last_config), 0) + 1
+            key = mode + ("j" if uj else "") + ("" if tb or mode == "edit" else " scores-only") + " " + kernel_class(al.last_config)
+            classes[key] = classes.get(key, 0) + 1
         for k, (a, b) in enumerate(pairs):
             r = O.align(O.MODE_NAMES[mode], a, b, *sc, uj, sites)
             ctx = (seed, batches, mode, sc, uj, sites, k, a, b, al.last_config)

@@ -98,16 +98,22 @@ def valu_roofline(workload, pairs, tb, kernel_config, steps, elapsed, cells_per_
     if stale:
         return dict(bound="valu", achieved=None, peak=None, unit="G wave-instr/s", frac=None, stale=stale,
                     source="profiles/%s/traffic_%s%s.json" % (PROFILE_ROUND, workload, "" if tb else "_scores")), None
-    # packed int16 kernels: every instruction of the step body is of the 4-cycle class; int32 kernels: mostly 2-cycle adds, priced
-    # with the full-rate 2.0 (the only bound that holds for any mix)
-    cyc = vi["roofline"]["cycles_per_inst"]["packed16" if "packed16" in kernel_config else "int32"]
+    # packed int16 kernels: every instruction of the step body is of the 4-cycle class; so are the bit-parallel edit kernel's
+    # (v_bitop3_b32, v_alignbit_b32) and the two instructions per cell of the int32 ramp sweeps (overlap scores only, cell-by-cell
+    # edit distance: v_add_u32_sdwa, v_max3_i32) -- classes the microbenchmark lists when it has measured them; the other int32
+    # kernels mix 2-cycle adds in and are priced with the full-rate 2.0 (the only bound that holds for any mix)
+    cpi = vi["roofline"]["cycles_per_inst"]
+    mode = WORKLOADS[workload][0]
+    cls = ("packed16" if "packed16" in kernel_config else "bitparallel" if kernel_config.startswith("myers")
+           else "int32_ramp" if (mode == "edit" or (mode == "overlap" and not tb)) else "int32")
+    cyc = cpi.get(cls, cpi["int32"])
     ghz = vi["roofline"]["clock_ghz"]
     simds = vi["roofline"]["simds"]
     peak = simds * ghz / cyc                      # G wave-instructions / s
     achieved = insts * steps / elapsed / 1e9
     out = dict(bound="valu", achieved=achieved, peak=peak, unit="G wave-instr/s", frac=achieved / peak,
                frac_at_documented_2_cycles=achieved / (simds * ghz / 2.0),
-               valu_insts_per_launch=insts, cycles_per_inst=cyc, cycles_per_inst_source=vi_src + " (this repository's microbenchmark tools/valu_issue.hip; "
+               valu_insts_per_launch=insts, cycles_per_inst=cyc, cycles_per_inst_class=cls, cycles_per_inst_source=vi_src + " (this repository's microbenchmark tools/valu_issue.hip; "
                "MI355X_MICROARCH.md documents the 2-cycle class only)", clock_ghz=ghz, simds=simds,
                insts_per_alignment=insts / pairs, insts_per_cell=insts / (pairs * cells_per_pair), kernel_source_sha16=src_sha,
                source="profiles/%s/traffic_%s%s.json + %s" % (PROFILE_ROUND, workload, "" if tb else "_scores", vi_src))

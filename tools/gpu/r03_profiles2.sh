@@ -4,6 +4,15 @@ set -e
 export TMPDIR=/tmp
 O=gpurun_out/r03q
 rm -rf $O; mkdir -p $O
+# the issue-rate microbenchmark once more (it prices the bit-parallel kernel with the cost of that kernel's own instruction mix), then the
+# bench lines that use those classes
+[ -x tools/bin/valu_issue ] || /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 tools/valu_issue.hip -o tools/bin/valu_issue
+tools/bin/valu_issue $O/valu_issue.json > $O/valu_issue.txt
+cp $O/valu_issue.json profiles/r03/valu_issue.json
+: > $O/workloads_bench_repriced.jsonl
+for W in C5all E1k E150; do
+  timeout -k 10 400 python3 bench.py --workload $W --steps 60 >> $O/workloads_bench_repriced.jsonl 2>> $O/bench.err
+done
 timeout -k 10 1100 python3 -m pytest tests -q -m gpu --durations=8 > $O/pytest_gpu_final.log 2>&1 || { tail -60 $O/pytest_gpu_final.log; exit 1; }
 tail -12 $O/pytest_gpu_final.log
 python3 -c "import __graft_entry__ as g; g.smoke()" > $O/smoke.log 2>&1 && tail -1 $O/smoke.log
@@ -32,10 +41,12 @@ with tempfile.TemporaryDirectory() as d:
 PY
 cat $O/cli_comm_trace.txt | cut -c1-120
 : > $O/fuzz_parity.txt
-for seed in 3101 3102 3103 3104 3105 3106; do
+for seed in 3301 3302 3303 3304; do
   timeout -k 10 900 python3 tests/fuzz_parity.py 60000 $seed >> $O/fuzz_parity.txt 2>&1 || { tail -30 $O/fuzz_parity.txt; exit 1; }
 done
-for seed in 3201 3202; do
+for seed in 3401; do
   AT_FUZZ_MODES=fitj,overlap timeout -k 10 900 python3 tests/fuzz_parity.py 60000 $seed >> $O/fuzz_parity.txt 2>&1 || { tail -30 $O/fuzz_parity.txt; exit 1; }
 done
+AT_FUZZ_MODES=overlap,edit AT_FUZZ_TB=0 timeout -k 10 600 python3 tests/fuzz_parity.py 60000 3501 >> $O/fuzz_parity.txt 2>&1 || { tail -30 $O/fuzz_parity.txt; exit 1; }
+AT_FUZZ_MODES=edit AT_FUZZ_EDIT_UNIT=1 AT_MYERS_LANE_MIN_PAIRS=1 timeout -k 10 600 python3 tests/fuzz_parity.py 60000 3601 >> $O/fuzz_parity.txt 2>&1 || { tail -30 $O/fuzz_parity.txt; exit 1; }
 grep -h "fuzz parity" $O/fuzz_parity.txt

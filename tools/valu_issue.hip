@@ -100,6 +100,7 @@ KERNEL(v_max3_f32, A3("v_max3_f32", ""))
 KERNEL(v_max3_i16, A3("v_max3_i16", ""))
 KERNEL(v_mad_i32_i24, A3("v_mad_i32_i24", ""))
 KERNEL(v_bfe_u32, A3("v_bfe_u32", ""))
+KERNEL(v_bitop3_b32, A3("v_bitop3_b32", " bitop3:0x96"))   /* gfx950: any function of three words (the bit-parallel edit kernel's step) */
 /* ---- VOP3P packed 16-bit ---- */
 KERNEL(v_pk_add_i16, A2("v_pk_add_i16", ""))
 KERNEL(v_pk_add_i16_clamp, A2("v_pk_add_i16", " clamp"))
@@ -124,6 +125,15 @@ KERNEL(mix_pkmax_addu32, AM("v_pk_max_i16", "v_add_u32"))
 KERNEL(mix_7pkmax_1or, A71("v_pk_max_i16", "v_or_b32"))
 KERNEL(mix_addu32_maxi32, AM("v_add_u32", "v_max_i32"))
 KERNEL(mix_addf32_maxf32, AM("v_add_f32", "v_max_f32"))
+/* the two instructions of a cell of the ramp sweeps (overlap scores only, cell-by-cell edit distance): v_add_u32_sdwa, v_max3_i32 */
+#define ASM3                                                                                                              \
+	"v_add_u32_sdwa %0, %0, %8 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_1\n" "v_max3_i32 %1, %1, %8, %9\n"   \
+	"v_add_u32_sdwa %2, %2, %8 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_1\n" "v_max3_i32 %3, %3, %8, %9\n"   \
+	"v_add_u32_sdwa %4, %4, %8 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_1\n" "v_max3_i32 %5, %5, %8, %9\n"   \
+	"v_add_u32_sdwa %6, %6, %8 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_1\n" "v_max3_i32 %7, %7, %8, %9\n"
+KERNEL(mix_sdwaadd_max3, ASM3)
+KERNEL(mix_bitop3_alignbit, "v_bitop3_b32 %0, %0, %8, %9 bitop3:0x96\n" "v_alignbit_b32 %1, %1, %8, %9\n" "v_bitop3_b32 %2, %2, %8, %9 bitop3:0xe8\n" "v_alignbit_b32 %3, %3, %8, %9\n"
+       "v_bitop3_b32 %4, %4, %8, %9 bitop3:0x96\n" "v_add_u32 %5, %5, %8\n" "v_bitop3_b32 %6, %6, %8, %9 bitop3:0xe8\n" "v_xor_b32 %7, %7, %8\n")
 
 typedef void (*kfn)(unsigned long long *, int *, int, int, int);
 struct Entry { const char *name; kfn f; };
@@ -133,11 +143,11 @@ static const Entry table[] = {
 	E(v_lshlrev_b32), E(v_ashrrev_i32), E(v_add_f32), E(v_max_f32), E(v_mul_f32), E(v_add_u16), E(v_max_i16), E(v_cndmask_vcc),
 	E(v_add_u32_e64), E(v_max_i32_e64), E(v_or_b32_e64), E(v_add_u32_sgpr), E(v_max_i32_sgpr), E(v_or_b32_sgpr),
 	E(v_max3_i32), E(v_med3_i32), E(v_and_or_b32), E(v_or3_b32), E(v_bfi_b32), E(v_perm_b32), E(v_alignbit_b32), E(v_lshl_or_b32),
-	E(v_lshl_add_u32), E(v_add3_u32), E(v_xad_u32), E(v_fma_f32), E(v_max3_f32), E(v_max3_i16), E(v_mad_i32_i24), E(v_bfe_u32),
+	E(v_lshl_add_u32), E(v_add3_u32), E(v_xad_u32), E(v_fma_f32), E(v_max3_f32), E(v_max3_i16), E(v_mad_i32_i24), E(v_bfe_u32), E(v_bitop3_b32),
 	E(v_pk_add_i16), E(v_pk_add_i16_clamp), E(v_pk_sub_i16_clamp), E(v_pk_max_i16), E(v_pk_min_u16), E(v_pk_mad_i16),
 	E(v_pk_lshlrev_b16), E(v_pk_ashrrev_i16), E(v_pk_add_f16), E(v_pk_max_f16),
 	E(v_mov_dpp_wave_shr1), E(v_mov_dpp_row_shr1), E(v_mov_dpp_row_shl1), E(v_add_u32_dpp_row_shr1), E(v_add_u32_sdwa),
-	E(mix_pkadd_pkmax), E(mix_pkmax_or), E(mix_pkmax_addu32), E(mix_7pkmax_1or), E(mix_addu32_maxi32), E(mix_addf32_maxf32),
+	E(mix_pkadd_pkmax), E(mix_pkmax_or), E(mix_pkmax_addu32), E(mix_7pkmax_1or), E(mix_addu32_maxi32), E(mix_addf32_maxf32), E(mix_sdwaadd_max3), E(mix_bitop3_alignbit),
 };
 
 #define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { fprintf(stderr, "%s: %s\n", #x, hipGetErrorString(e_)); return 1; } } while (0)
@@ -165,6 +175,7 @@ int main(int argc, char **argv)
 	hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
 	bool first = true;
 	std::vector<double> all_ghz, half_rate_cost;
+	double bitpar_cost = 1e9;   /* cheapest wall cost of the bit-parallel kernel's instruction mix */
 	for (const Entry &en : table) {
 		printf("%-26s", en.name);
 		js += std::string(first ? "" : ",\n") + "  \"" + en.name + "\": {";
@@ -194,6 +205,7 @@ int main(int argc, char **argv)
 			if (wi >= 1) {
 				all_ghz.push_back(g);
 				if (strncmp(en.name, "v_pk_", 5) == 0 || strcmp(en.name, "mix_pkadd_pkmax") == 0) half_rate_cost.push_back(wall);
+				if (strcmp(en.name, "mix_bitop3_alignbit") == 0) bitpar_cost = std::min(bitpar_cost, wall);
 			}
 		}
 		js += "}";
@@ -202,16 +214,21 @@ int main(int argc, char **argv)
 	/* what bench.py prices SQ_INSTS_VALU with.  The step body of the sweep kernels is made of VOP3P packed 16-bit
 	 * operations, VOP3 bit-field operations and DPP moves: each occupies a SIMD for 4 cycles (64 lanes over 16 lanes per
 	 * cycle), and the 2-cycle VOP2 operations mixed in between cost 4 as well (the mix_* rows): cycles_per_inst.packed16 is
-	 * that architectural 4.0.  The int32 kernels (overlap, edit, long pairs) are mostly 2-cycle VOP2 adds with 4-cycle max3 /
-	 * DPP in between and run FASTER than 4 cycles per instruction; they are priced with the 2.0 of the full-rate class, the
-	 * only bound that holds for every mix.  measured_packed16_cost is what this run saw for the packed operations alone at 2-4 waves per SIMD
-	 * (loop overhead and clock ramp included); clock_ghz is the median clock the chip held under these loads. */
+	 * that architectural 4.0.  The bit-parallel edit kernel's word step is eleven VOP3 operations (v_bitop3_b32, v_alignbit_b32) and
+	 * three VOP2 ones, which pair up across waves now and then: cycles_per_inst.bitparallel is the cheapest this run saw for that mix
+	 * (row mix_bitop3_alignbit: six VOP3, two VOP2), a little under 4.  The int32 kernels mix 2-cycle VOP2 operations into 4-cycle
+	 * ones in every proportion -- the ramp sweeps (overlap scores only, cell-by-cell edit distance: v_add_u32_sdwa + v_max3_i32 per
+	 * cell, rows mix_sdwaadd_max3 and mix_addu32_maxi32) run at 3.7 cycles per instruction, what 85 percent 4-cycle operations come
+	 * to -- and keep the 2.0 of the full-rate class, the only bound that holds for every mix (int32, int32_ramp).
+	 * measured_packed16_cost is what this run saw for the packed operations alone at 2-4 waves per SIMD (loop overhead and clock
+	 * ramp included); clock_ghz is the median clock the chip held under these loads. */
 	std::sort(all_ghz.begin(), all_ghz.end());
 	std::sort(half_rate_cost.begin(), half_rate_cost.end());
+	if (!(bitpar_cost > 2.0 && bitpar_cost < 4.0)) bitpar_cost = 4.0;
 	char rb[512];
-	snprintf(rb, sizeof rb, "\n },\n \"roofline\": {\"cycles_per_inst\": {\"packed16\": 4.0, \"int32\": 2.0}, \"clock_ghz\": %.3f, \"simds\": %d, "
+	snprintf(rb, sizeof rb, "\n },\n \"roofline\": {\"cycles_per_inst\": {\"packed16\": 4.0, \"int32\": 2.0, \"bitparallel\": %.3f, \"int32_ramp\": 2.0}, \"clock_ghz\": %.3f, \"simds\": %d, "
 	         "\"measured_packed16_cost\": {\"min\": %.3f, \"median\": %.3f, \"max\": %.3f}}\n}\n",
-	         all_ghz[all_ghz.size() / 2], cus * 4, half_rate_cost.front(), half_rate_cost[half_rate_cost.size() / 2], half_rate_cost.back());
+	         bitpar_cost, all_ghz[all_ghz.size() / 2], cus * 4, half_rate_cost.front(), half_rate_cost[half_rate_cost.size() / 2], half_rate_cost.back());
 	js += rb;
 	if (json_path) {
 		FILE *f = fopen(json_path, "w");

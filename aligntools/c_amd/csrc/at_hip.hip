@@ -102,6 +102,7 @@ struct at_handle {
 	void *hp_blob = nullptr; size_t hp_blob_bytes = 0;
 	void *hp_out = nullptr; size_t hp_out_bytes = 0;
 	void *hp_flag = nullptr;
+	void *hp_order = nullptr; size_t hp_order_bytes = 0;   /* the processing order of a ragged batch */
 	double last_payload_per_pair = 16.0;   /* traceback bytes per pair of the latest batch: how much payload the next one fetches unasked */
 	/* all-vs-all in slices: a copy stream, pinned result buffers (two sets, used in turn) and their events */
 	hipStream_t copy_stream = nullptr;
@@ -209,6 +210,7 @@ extern "C" void at_destroy(at_handle *h)
 	if (h->hp_blob) (void)hipHostFree(h->hp_blob);
 	if (h->hp_out) (void)hipHostFree(h->hp_out);
 	if (h->hp_flag) (void)hipHostFree(h->hp_flag);
+	if (h->hp_order) (void)hipHostFree(h->hp_order);
 	for (int q = 0; q < 2; ++q) {
 		if (h->ev_sweep[q]) (void)hipEventDestroy(h->ev_sweep[q]);
 		if (h->ev_copy[q]) (void)hipEventDestroy(h->ev_copy[q]);
@@ -1114,22 +1116,33 @@ static int align_host(at_handle *h, int mode, int64_t npairs, const uint8_t *seq
 	const unsigned pgrid = (unsigned)std::min<int64_t>((2 * npairs + 15) / 16, 8LL * h->ncu);
 	int bits = force8 ? 8 : 2;
 	int *p_flag = (int *)((char *)h->hp_flag);
+	bool flag_pending = false;
 	if (bits == 2) {
 		HIP_TRY(h, hipMemsetAsync(d_flag, 0, 4, s));
 		hipLaunchKernelGGL(at::at_pack<2>, dim3(pgrid), dim3(256), 0, s, pa);
 		HIP_TRY(h, hipMemcpyAsync(p_flag, d_flag, 4, hipMemcpyDeviceToHost, s));
-		htrace("chunk: uploads and packing queued, pair", pair_base);
-		HIP_TRY(h, hipStreamSynchronize(s));
-		htrace("chunk: packed, pair", pair_base);
-		if (*p_flag) {                                 /* some byte is not one of ACGT: byte words, byte kernels */
-			bits = 8;
-			HIP_TRY(h, hipMemcpyAsync(d_swoff, p_sw8, 2 * n * 8, hipMemcpyHostToDevice, s));
-		}
+		flag_pending = true;
 	}
-	if (bits == 8) hipLaunchKernelGGL(at::at_pack<8>, dim3(pgrid), dim3(256), 0, s, pa);
-	hipLaunchKernelGGL(at::at_split_desc, dim3((unsigned)std::min<int64_t>((npairs + 255) / 256, 8LL * h->ncu)), dim3(256), 0, s,
-	                   (const long long *)d_swoff, (const int *)d_slen, (long long)npairs, (long long *)d_woff1, (long long *)d_woff2, d_len1, d_len2);
-	HIP_TRY(h, hipGetLastError());
+	htrace("chunk: uploads and packing queued, pair", pair_base);
+	/* The alphabet of the batch is known when the packing kernel's flag is down -- one wait for the uploads per chunk.  A ragged
+	 * batch makes its plan (frames, the order of the pairs: host work over the lengths alone) BEFORE that wait, for the 2-bit
+	 * alphabet it expects, and again only if the flag says otherwise. */
+	auto settle_alphabet = [&]() -> int {
+		if (flag_pending) {
+			HIP_TRY(h, hipStreamSynchronize(s));
+			htrace("chunk: packed, pair", pair_base);
+			flag_pending = false;
+			if (*p_flag) {                                 /* some byte is not one of ACGT: byte words, byte kernels */
+				bits = 8;
+				HIP_TRY(h, hipMemcpyAsync(d_swoff, p_sw8, 2 * n * 8, hipMemcpyHostToDevice, s));
+			}
+		}
+		if (bits == 8) hipLaunchKernelGGL(at::at_pack<8>, dim3(pgrid), dim3(256), 0, s, pa);
+		hipLaunchKernelGGL(at::at_split_desc, dim3((unsigned)std::min<int64_t>((npairs + 255) / 256, 8LL * h->ncu)), dim3(256), 0, s,
+		                   (const long long *)d_swoff, (const int *)d_slen, (long long)npairs, (long long *)d_woff1, (long long *)d_woff2, d_len1, d_len2);
+		HIP_TRY(h, hipGetLastError());
+		return AT_OK;
+	};
 	const size_t b_len1 = al((size_t)npairs * 4);
 	/* device output block: score | end_i | end_j | state | nops | ops */
 	const size_t b_ops = al((size_t)ops_total + 64), b_pfx = al((size_t)(npairs + 1) * 8);
@@ -1155,9 +1168,12 @@ static int align_host(at_handle *h, int mode, int64_t npairs, const uint8_t *seq
 	int *d_order = nullptr;
 	bool frames = false;
 	std::vector<int> order;
-	if (!uniform && npairs > 1 && npairs < (1LL << 31)) {
-		order.resize((size_t)npairs);
-		for (int64_t k = 0; k < npairs; ++k) order[(size_t)k] = (int)k;
+	const bool ragged = !uniform && npairs > 1 && npairs < (1LL << 31);
+	if (!ragged) {
+		rc = settle_alphabet();
+		if (rc) return rc;
+	}
+	if (ragged) {
 		int th = 0, min1 = INT32_MAX, min2 = INT32_MAX;
 		for (int64_t k = 0; k < npairs; ++k) { min1 = std::min(min1, len1[k]); min2 = std::min(min2, len2[k]); }
 		const bool affine = mode == AT_MODE_LOCAL || mode == AT_MODE_GLOBAL || mode == AT_MODE_FIT;
@@ -1167,8 +1183,6 @@ static int align_host(at_handle *h, int mode, int64_t npairs, const uint8_t *seq
 		/* the longest read with a one-strip frame: 32 lanes x 19 rows for local, x 16 for global, x 13 for fit (the uniform kernels'
 		 * classes, layout16_for); overlap: 64 lanes x 16 rows */
 		const int max_rag = mode == AT_MODE_LOCAL ? 608 : mode == AT_MODE_GLOBAL ? 512 : mode == AT_MODE_FIT ? 416 : 1024;
-		frames = (affine || ovl) && max1 <= max_rag && min1 >= 1 && min2 >= 1 && npairs >= 64 && env_ll("AT_RAGGED_PACKED", 1) &&
-		         packed_ok(h, mode, bits, max1, max2, ovl ? 2 : 4, &th);
 		/* (group width, rows per lane) of a read length.  Local frames mix read lengths freely and run on the 16-lane groups up to
 		 * 304 bases (on the 8-lane groups, whose lanes carry up to 19 rows, the same batches ran 15 % slower: 100..150 x 100..150 2.9
 		 * against 2.5 ms per 100k pairs), on the 32-lane groups beyond; global / fit: 8-lane groups up to 152 bases, 16-lane up to
@@ -1180,58 +1194,74 @@ static int align_host(at_handle *h, int mode, int64_t npairs, const uint8_t *seq
 			if (mode == AT_MODE_LOCAL) return l1 <= 64 ? 4 : l1 <= 80 ? 5 : l1 <= 96 ? 6 : l1 <= 112 ? 7 : l1 <= 160 ? 10 : l1 <= 208 ? 13 : l1 <= 256 ? 16 : 19;
 			return l1 <= 40 ? 5 : l1 <= 48 ? 6 : l1 <= 56 ? 7 : l1 <= 64 ? 8 : l1 <= 80 ? 10 : l1 <= 104 ? 13 : l1 <= 128 ? 16 : l1 <= 152 ? 19 : l1 <= 160 ? 10 : l1 <= 208 ? 13 : l1 <= 256 ? 16 : 19;
 		};
-		/* every frame is at most max1 x max2: if a class has no packed kernel for that (s2 too long for LDS), none is tried */
-		if (frames) {
-			const bool hasj = kmode_f == at::K_FITJ;
-			const int tsf = ovl ? 2 : 4;
-			const int tops[4] = {std::min(max1, 152), std::min(max1, 304), std::min(max1, 608), max1};
-			for (int q = 0; q < 4 && frames; ++q) {
-				const int l1q = ovl ? max1 : tops[q];
-				if (l1q < min1 || (q > 0 && !ovl && tops[q] == tops[q - 1])) continue;
-				const int g = gclass(l1q);
-				frames = packed16_kernel_exists(kmode_f, layout16_for(tb, hasj, l1q, max2, tsf, g, ovl, kmode_f, ovl ? kclass(l1q) : 0), tb, tsf, bits, g);
-				if (ovl) break;
+		for (int pass = 0; pass < 2; ++pass) {   /* (the second pass: the batch was not pure ACGT after all) */
+			const int planned_bits = bits;
+			order.resize((size_t)npairs);
+			for (int64_t k = 0; k < npairs; ++k) order[(size_t)k] = (int)k;
+			frames = (affine || ovl) && max1 <= max_rag && min1 >= 1 && min2 >= 1 && npairs >= 64 && env_ll("AT_RAGGED_PACKED", 1) &&
+			         packed_ok(h, mode, bits, max1, max2, ovl ? 2 : 4, &th);
+			/* every frame is at most max1 x max2: if a class has no packed kernel for that (s2 too long for LDS), none is tried */
+			if (frames) {
+				const bool hasj = kmode_f == at::K_FITJ;
+				const int tsf = ovl ? 2 : 4;
+				const int tops[4] = {std::min(max1, 152), std::min(max1, 304), std::min(max1, 608), max1};
+				for (int q = 0; q < 4 && frames; ++q) {
+					const int l1q = ovl ? max1 : tops[q];
+					if (l1q < min1 || (q > 0 && !ovl && tops[q] == tops[q - 1])) continue;
+					const int g = gclass(l1q);
+					frames = packed16_kernel_exists(kmode_f, layout16_for(tb, hasj, l1q, max2, tsf, g, ovl, kmode_f, ovl ? kclass(l1q) : 0), tb, tsf, bits, g);
+					if (ovl) break;
+				}
 			}
+			if (frames && mode == AT_MODE_LOCAL) {
+				/* (class descending, l2 descending, index ascending): a counting sort -- the key space is 13 x (max2 + 1) */
+				auto kidx = [&](int l1) {   /* classes in descending order of rows */
+					if (l1 > 304) { const int kc = kclass(l1); return kc == 19 ? 0 : kc == 16 ? 1 : kc == 13 ? 2 : kc == 12 ? 3 : 4; }
+					const int kc = kclass(l1);
+					return 5 + (kc == 19 ? 0 : kc == 16 ? 1 : kc == 13 ? 2 : kc == 10 ? 3 : kc == 7 ? 4 : kc == 6 ? 5 : kc == 5 ? 6 : 7);
+				};
+				const size_t span = (size_t)max2 + 1;
+				std::vector<int> start(13 * span + 1, 0);
+				for (int64_t k = 0; k < npairs; ++k) ++start[(size_t)kidx(len1[k]) * span + (size_t)(max2 - len2[k]) + 1];
+				for (size_t q = 1; q < start.size(); ++q) start[q] += start[q - 1];
+				for (int64_t k = 0; k < npairs; ++k) order[(size_t)start[(size_t)kidx(len1[k]) * span + (size_t)(max2 - len2[k])]++] = (int)k;
+			} else if (frames) {
+				/* (l1 descending, l2 descending, index ascending) by counting sort, then every run of equal l1 padded to whole
+				 * work items (16 alignments on the 8-lane groups, 8 on the 16-lane groups, 4 on the 32-lane groups, 2 on the 64-lane group) */
+				const size_t span = (size_t)max2 + 1;
+				std::vector<int> start((size_t)(max1 + 1) * span + 1, 0);
+				for (int64_t k = 0; k < npairs; ++k) ++start[(size_t)(max1 - len1[k]) * span + (size_t)(max2 - len2[k]) + 1];
+				for (size_t q = 1; q < start.size(); ++q) start[q] += start[q - 1];
+				std::vector<int> sorted((size_t)npairs);
+				for (int64_t k = 0; k < npairs; ++k) sorted[(size_t)start[(size_t)(max1 - len1[k]) * span + (size_t)(max2 - len2[k])]++] = (int)k;
+				order.clear();
+				for (size_t b0 = 0; b0 < sorted.size();) {
+					size_t b1 = b0;
+					const size_t run0 = order.size();
+					while (b1 < sorted.size() && len1[sorted[b1]] == len1[sorted[b0]]) order.push_back(sorted[b1++]);
+					const size_t per = (size_t)(2 * (64 / gclass(len1[sorted[b0]])));
+					while ((order.size() - run0) % per) order.push_back(~sorted[b1 - 1]);   /* ~index: swept, not stored (at_sweep16.hip.h) */
+					b0 = b1;
+				}
+			} else
+				std::stable_sort(order.begin(), order.end(), [&](int x, int y) {
+					return (int64_t)len1[x] * len2[x] > (int64_t)len1[y] * len2[y];
+				});
+			if (pass == 0) {
+				rc = settle_alphabet();
+				if (rc) return rc;
+			}
+			if (bits == planned_bits) break;
 		}
-		if (frames && mode == AT_MODE_LOCAL) {
-			/* (class descending, l2 descending, index ascending): a counting sort -- the key space is 13 x (max2 + 1) */
-			auto kidx = [&](int l1) {   /* classes in descending order of rows */
-				if (l1 > 304) { const int kc = kclass(l1); return kc == 19 ? 0 : kc == 16 ? 1 : kc == 13 ? 2 : kc == 12 ? 3 : 4; }
-				const int kc = kclass(l1);
-				return 5 + (kc == 19 ? 0 : kc == 16 ? 1 : kc == 13 ? 2 : kc == 10 ? 3 : kc == 7 ? 4 : kc == 6 ? 5 : kc == 5 ? 6 : 7);
-			};
-			const size_t span = (size_t)max2 + 1;
-			std::vector<int> start(13 * span + 1, 0);
-			for (int64_t k = 0; k < npairs; ++k) ++start[(size_t)kidx(len1[k]) * span + (size_t)(max2 - len2[k]) + 1];
-			for (size_t q = 1; q < start.size(); ++q) start[q] += start[q - 1];
-			for (int64_t k = 0; k < npairs; ++k) order[(size_t)start[(size_t)kidx(len1[k]) * span + (size_t)(max2 - len2[k])]++] = (int)k;
-		} else if (frames) {
-			/* (l1 descending, l2 descending, index ascending) by counting sort, then every run of equal l1 padded to whole
-			 * work items (16 alignments on the 8-lane groups, 8 on the 16-lane groups, 4 on the 32-lane groups, 2 on the 64-lane group) */
-			const size_t span = (size_t)max2 + 1;
-			std::vector<int> start((size_t)(max1 + 1) * span + 1, 0);
-			for (int64_t k = 0; k < npairs; ++k) ++start[(size_t)(max1 - len1[k]) * span + (size_t)(max2 - len2[k]) + 1];
-			for (size_t q = 1; q < start.size(); ++q) start[q] += start[q - 1];
-			std::vector<int> sorted((size_t)npairs);
-			for (int64_t k = 0; k < npairs; ++k) sorted[(size_t)start[(size_t)(max1 - len1[k]) * span + (size_t)(max2 - len2[k])]++] = (int)k;
-			order.clear();
-			for (size_t b0 = 0; b0 < sorted.size();) {
-				size_t b1 = b0;
-				const size_t run0 = order.size();
-				while (b1 < sorted.size() && len1[sorted[b1]] == len1[sorted[b0]]) order.push_back(sorted[b1++]);
-				const size_t per = (size_t)(2 * (64 / gclass(len1[sorted[b0]])));
-				while ((order.size() - run0) % per) order.push_back(~sorted[b1 - 1]);   /* ~index: swept, not stored (at_sweep16.hip.h) */
-				b0 = b1;
-			}
-		} else
-			std::stable_sort(order.begin(), order.end(), [&](int x, int y) {
-				return (int64_t)len1[x] * len2[x] > (int64_t)len1[y] * len2[y];
-			});
+		htrace("chunk: planned, pair", pair_base);
+		/* the order goes up from page-locked memory: nothing to wait for on the host */
 		rc = grow(h, &h->d_order, &h->order_bytes, order.size() * 4);
 		if (rc) return rc;
+		rc = grow_pinned(h, &h->hp_order, &h->hp_order_bytes, order.size() * 4);
+		if (rc) return rc;
+		memcpy(h->hp_order, order.data(), order.size() * 4);
 		d_order = (int *)h->d_order;
-		HIP_TRY(h, hipMemcpyAsync(d_order, order.data(), order.size() * 4, hipMemcpyHostToDevice, s));
-		HIP_TRY(h, hipStreamSynchronize(s));
+		HIP_TRY(h, hipMemcpyAsync(d_order, h->hp_order, order.size() * 4, hipMemcpyHostToDevice, s));
 		if (frames && mode == AT_MODE_LOCAL) {
 			const int64_t min_bucket = env_ll("AT_RAGGED_MIN_BUCKET", 4096);
 			int nb = 0;

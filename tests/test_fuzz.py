@@ -22,6 +22,26 @@ def test_fuzz_campaign(seed):
     assert n >= 1500
 
 
+@pytest.mark.parametrize("aim", ["overlap and edit, scores only (the sweeps on the gap ramp)", "edit -u 1 (every form of the bit-parallel kernel)"])
+def test_fuzz_campaign_aimed(aim):
+    """Round 3's new sweeps get a campaign of their own: overlap without tracebacks and cell-by-cell edit distance (at_sweep.hip.h, RAMP),
+    and the bit-parallel kernel with one alignment per lane in all four widths (AT_MYERS_LANE_MIN_PAIRS = 1: small batches too)."""
+    import fuzz_parity
+    env = ({"AT_FUZZ_MODES": "overlap,edit", "AT_FUZZ_TB": "0"} if aim.startswith("overlap")
+           else {"AT_FUZZ_MODES": "edit", "AT_FUZZ_EDIT_UNIT": "1", "AT_MYERS_LANE_MIN_PAIRS": "1"})
+    os.environ.update(env)
+    seen = {}
+    try:
+        n = fuzz_parity.run(int(os.environ.get("AT_FUZZ_CASES", "1500")), 31 if aim.startswith("overlap") else 32, verbose=False, classes=seen)
+    finally:
+        for k in env:
+            del os.environ[k]
+    assert n >= 1500
+    keys = " | ".join(seen)
+    for family in (("overlap scores-only int32", "edit int32") if aim.startswith("overlap") else ("myers W5 64x1", "myers W8 64x1", "myers W16 64x1", "myers W32 64x1")):
+        assert family in keys, (family, sorted(seen))
+
+
 def test_fuzz_campaign_reached_every_kernel_family():
     """(runs behind the four campaigns of this module) what their batches ran on, by at_last_config"""
     if len(SEEN) == 0:

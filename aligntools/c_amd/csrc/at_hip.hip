@@ -1095,9 +1095,11 @@ static int align_host(at_handle *h, int mode, int64_t npairs, const uint8_t *seq
 		rc = grow_pinned(h, &h->hp_blob, &h->hp_blob_bytes, (size_t)blob_bytes + 64);
 		if (rc) return rc;
 	}
-	/* (Tried and dropped: the chunks of a batch uploading in order -- own streams chained by events, or one copy stream with the
-	 * threads waiting on the host for their own copies -- so that each crosses the link at its full rate and the first sweep
-	 * starts early: 2.28 / 2.37 ms per 100k pairs of C2 against 2.17 side by side, all within the noise of the box.) */
+	/* (Tried and dropped, twice: the chunks of a batch uploading in order -- own streams chained by events, or one copy stream with
+	 * the threads waiting on the host for their own copies -- so that each crosses the link at its full rate and the first sweep
+	 * starts early.  Round 2: 2.28 / 2.37 ms per 100k pairs of C2 against 2.17 side by side.  Round 3, medians of 50 calls on one box:
+	 * 1.90-2.12 ms against 1.99-2.04 with tracebacks, and 1.65-1.77 against 1.21-1.37 scores only -- copies queued side by side on six
+	 * streams move more bytes per second than the same copies one behind the other.) */
 	HIP_TRY(h, hipMemcpyAsync(dd, hd, up_bytes, hipMemcpyHostToDevice, s));
 	if (caller_pinned) HIP_TRY(h, hipMemcpyAsync(d_blob, up_src, (size_t)blob_bytes, hipMemcpyHostToDevice, s));
 	else {

@@ -906,18 +906,20 @@ static int align_device(at_handle *h, int mode, int64_t npairs,
 	}
 
 	/* ---- edit distance with unit mismatch cost: bit-parallel kernel (at_myers.hip.h), any mix of lengths ---- */
-	if (kmode == at::K_EDIT && h->u == 1 && bits == 2 && ap_n == 0 && max_len1 <= 8192 && env_ll("AT_MYERS", 1)) {
+	/* (bytes of LDS for the s2 windows of the n alignments of a wavefront; two must fit, or the cell-by-cell kernel takes the batch) */
+	auto myers_windows = [&](int n) { return (size_t)n * ((((size_t)max_len2 + 15) / 16 + 2) | 1) * 4; };
+	if (kmode == at::K_EDIT && h->u == 1 && bits == 2 && ap_n == 0 && max_len1 <= 32768 && myers_windows(2) <= 60 * 1024 && env_ll("AT_MYERS", 1)) {
 		/* lanes per alignment and words per lane: reads of up to AT_MYERS_LANE_MAX (1 024) bases one alignment per LANE -- 5, 8, 16 or 32
 		 * words, 64 s2 windows in LDS (second sequences of up to ~3 500 bases) -- else 32 lanes; the 16- and 32-word forms only for batches
 		 * of AT_MYERS_LANE_MIN_PAIRS (16 384: one wavefront per CU) and more -- 10 000 pairs of 1 000 x 1 000 are 157 wavefronts on 1 024
 		 * SIMDs, 19 TCUPS against 31 on 32-lane groups; 131 072 of them 43 against 36.  AT_MYERS_GROUP = 8: the round-2 form, eight lanes
 		 * for reads of up to 256 bases and 32 beyond (A/B) */
 		const long long lane_max = env_ll("AT_MYERS_LANE_MAX", 1024);
-		const bool per_lane = max_len1 <= lane_max && max_len1 <= 1024 && (size_t)64 * ((((size_t)max_len2 + 15) / 16 + 2) | 1) * 4 <= 60 * 1024 &&
+		const bool per_lane = max_len1 <= lane_max && max_len1 <= 1024 && myers_windows(64) <= 60 * 1024 &&
 		                      (max_len1 <= 256 || npairs >= env_ll("AT_MYERS_LANE_MIN_PAIRS", 16384)) && env_ll("AT_MYERS_GROUP", 1) == 1;
-		const int g = per_lane ? 1 : max_len1 <= 256 ? 8 : 32;
+		const int g = per_lane ? 1 : max_len1 <= 256 && myers_windows(8) <= 60 * 1024 ? 8 : 32;
 		const int w = per_lane ? (max_len1 <= 160 ? 5 : max_len1 <= 256 ? 8 : max_len1 <= 512 ? 16 : 32)
-		            : max_len1 <= 1024 ? 1 : max_len1 <= 2048 ? 2 : max_len1 <= 4096 ? 4 : 8;
+		            : max_len1 <= 1024 ? 1 : max_len1 <= 2048 ? 2 : max_len1 <= 4096 ? 4 : max_len1 <= 8192 ? 8 : max_len1 <= 16384 ? 16 : 32;
 		at_myers_fn fn = at_pick_myers(w, g);
 		const int per_wave = 64 / g;
 		at::MyersArgs m;
@@ -930,7 +932,7 @@ static int align_device(at_handle *h, int mode, int64_t npairs,
 		if (!h->d_queue) HIP_TRY(h, hipMalloc((void **)&h->d_queue, 64));
 		HIP_TRY(h, hipMemsetAsync(h->d_queue, 0, 8, stream));
 		m.queue = h->d_queue;
-		const size_t lds = (size_t)per_wave * ((((size_t)max_len2 + 15) / 16 + 2) | 1) * 4;   /* (odd window stride, as the kernel computes it) */
+		const size_t lds = myers_windows(per_wave);   /* (odd window stride, as the kernel computes it) */
 		if (lds > 60 * 1024) return fail(h, AT_ERR_RANGE, "second sequence too long for the bit-parallel kernel's LDS window");
 		int occ = 0;
 		if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, (const void *)fn, 64, lds) != hipSuccess || occ <= 0) occ = 8;

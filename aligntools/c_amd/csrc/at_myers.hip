@@ -1,6 +1,6 @@
 #include "at_myers.hip.h"
 #include "at_launch.h"
-/* bit-parallel edit distance: W words of 32 rows per lane, G lanes per alignment (l1 <= 32 * G * W) */
+/* bit-parallel edit distance: W words of 32 rows per lane, G lanes per alignment (l1 <= 32 * G * W: up to 32 768 bases) */
 at_myers_fn at_pick_myers(int w, int g)
 {
 	if (g == 1)   /* one alignment per lane: reads up to 160 / 256 / 512 / 1 024 bases */
@@ -11,6 +11,8 @@ at_myers_fn at_pick_myers(int w, int g)
 	case 2: return at::at_myers<2, 32>;
 	case 4: return at::at_myers<4, 32>;
 	case 8: return at::at_myers<8, 32>;
+	case 16: return at::at_myers<16, 32>;   /* reads up to 16 384 / 32 768 bases */
+	case 32: return at::at_myers<32, 32>;
 	default: return nullptr;
 	}
 }

@@ -1069,7 +1069,7 @@ def test_all_vs_all_streamed_in_slices(al):
 
 def test_bit_parallel_edit_distance(al):
     """`edit -u 1` (unit mismatch cost: Levenshtein) runs on the bit-parallel kernel (at_myers.hip.h): every word / lane
-    boundary of l1 (32, 1024, 2048, 4096 rows), ragged and uniform batches, unrelated and related pairs, empty sequences,
+    boundary of l1 (32, 1024, 2048, 4096, 8192, 16384 rows), ragged and uniform batches, unrelated and related pairs, empty sequences,
     against the oracle; any other -u keeps the cell-by-cell kernel."""
     rng = random.Random(404)
     dna = lambda n: "".join(rng.choice("ACGT") for _ in range(n))
@@ -1085,7 +1085,7 @@ def test_bit_parallel_edit_distance(al):
             else:
                 t.insert(q, rng.choice("ACGT"))
         return "".join(t)
-    lens = [1, 2, 15, 16, 17, 31, 32, 33, 63, 64, 65, 100, 511, 512, 513, 1000, 1023, 1024, 1025, 1500, 2047, 2048, 2049, 3000, 4096, 4097, 5000, 8192]
+    lens = [1, 2, 15, 16, 17, 31, 32, 33, 63, 64, 65, 100, 511, 512, 513, 1000, 1023, 1024, 1025, 1500, 2047, 2048, 2049, 3000, 4096, 4097, 5000, 8192, 8193, 12000, 16384, 16385, 20000]
     ragged = []
     for n in lens:
         a = dna(n)
@@ -1095,7 +1095,7 @@ def test_bit_parallel_edit_distance(al):
     ragged += [("", "ACGT"), ("ACG", ""), ("", "")]
     al.set_scoring(1, 1, -5, -1)
     res = al.align_batch("edit", ragged)
-    assert "myers" in al.last_config and "words/lane=8" in al.last_config, al.last_config
+    assert "myers" in al.last_config and "words/lane=32" in al.last_config, al.last_config   # (20 000 rows: 32 lanes x 32 words)
     for k, (a, b) in enumerate(ragged):
         assert int(res["score"][k]) == O.align(O.EDIT, a, b, 1, 1, -5, -1)["score"], (k, len(a), len(b))
     # reads of up to 256 bases: one alignment per LANE (64 per wavefront), 5 words for up to 160 bases, 8 beyond; a second sequence too
@@ -1135,8 +1135,10 @@ def test_bit_parallel_edit_distance(al):
     res = al.align_batch("edit", ragged[:20])
     assert "int32" in al.last_config
     al.set_scoring(1, 1, -5, -1)
-    res = al.align_batch("edit", [(dna(8193), dna(100))])          # longer than the bit-parallel kernel takes
-    assert "int32" in al.last_config
+    for l1, l2 in ((32769, 100), (500, 125000)):                  # longer than the bit-parallel kernel takes / than its LDS windows hold
+        a, b = dna(l1), dna(l2)
+        res = al.align_batch("edit", [(a, b)])
+        assert "int32" in al.last_config and int(res["score"][0]) == O.align(O.EDIT, a, b, 1, 1, -5, -1)["score"], al.last_config
 
 
 def test_device_entry_detects_uniform_batches_itself(al):

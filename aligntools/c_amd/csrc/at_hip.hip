@@ -908,7 +908,7 @@ static int align_device(at_handle *h, int mode, int64_t npairs,
 	/* ---- edit distance with unit mismatch cost: bit-parallel kernel (at_myers.hip.h), any mix of lengths ---- */
 	/* (bytes of LDS for the s2 windows of the n alignments of a wavefront; two must fit, or the cell-by-cell kernel takes the batch) */
 	auto myers_windows = [&](int n) { return (size_t)n * ((((size_t)max_len2 + 15) / 16 + 2) | 1) * 4; };
-	if (kmode == at::K_EDIT && h->u == 1 && bits == 2 && ap_n == 0 && max_len1 <= 32768 && myers_windows(2) <= 60 * 1024 && env_ll("AT_MYERS", 1)) {
+	if (kmode == at::K_EDIT && h->u == 1 && bits == 2 && max_len1 <= 32768 && myers_windows(2) <= 60 * 1024 && env_ll("AT_MYERS", 1)) {
 		/* lanes per alignment and words per lane: reads of up to AT_MYERS_LANE_MAX (1 024) bases one alignment per LANE -- 5, 8, 16 or 32
 		 * words, 64 s2 windows in LDS (second sequences of up to ~3 500 bases) -- else 32 lanes; the 16- and 32-word forms only for batches
 		 * of AT_MYERS_LANE_MIN_PAIRS (16 384: one wavefront per CU) and more -- 10 000 pairs of 1 000 x 1 000 are 157 wavefronts on 1 024
@@ -929,6 +929,7 @@ static int align_device(at_handle *h, int mode, int64_t npairs,
 		m.max_l1 = max_len1; m.max_l2 = max_len2;
 		m.score = d_score; m.end_i = d_end_i; m.end_j = d_end_j; m.state = d_state; m.nops = d_nops;
 		m.order = d_order;
+		m.ap_n = ap_n; m.ap_first = ap_first;
 		if (!h->d_queue) HIP_TRY(h, hipMalloc((void **)&h->d_queue, 64));
 		HIP_TRY(h, hipMemsetAsync(h->d_queue, 0, 8, stream));
 		m.queue = h->d_queue;

@@ -32,6 +32,9 @@ struct MyersArgs {
 	int *score, *end_i, *end_j, *state, *nops;
 	const int *order;              /* optional processing order (largest pairs first) */
 	unsigned long long *queue;
+	/* all-vs-all over one read set (woff1 / len1 per READ): pair p of this launch is entry ap_first + p of the strict upper triangle of
+	 * ap_n reads, enumerated here like in at_sweep (no per-pair descriptors); ap_n = 0: pairs from the four arrays */
+	long long ap_n, ap_first;
 };
 
 /* bit k of the result = bit 2k of `w`, k = 0..15 (one bit plane of sixteen 2-bit codes) */
@@ -73,8 +76,10 @@ __global__ __launch_bounds__(64) void at_myers(const MyersArgs a)
 		const long long pin = wk * NG + grp;
 		const bool have = pin < a.npairs;
 		const long long p = a.order ? (long long)a.order[have ? pin : a.npairs - 1] : (have ? pin : a.npairs - 1);
-		const int l1 = a.len1[p], l2 = a.len2[p];
-		const uint32_t *q = a.seq + a.woff1[p], *r = a.seq + a.woff2[p];
+		long long ia = p, ib = p;
+		if (a.ap_n > 0) tri_pair(a.ap_first + p, a.ap_n, ia, ib);
+		const int l1 = a.len1[ia], l2 = a.ap_n > 0 ? a.len1[ib] : a.len2[ib];
+		const uint32_t *q = a.seq + a.woff1[ia], *r = a.seq + (a.ap_n > 0 ? a.woff1[ib] : a.woff2[ib]);
 		const bool fits = l1 >= 0 && l2 >= 0 && l1 <= 32 * G * W && l2 <= a.max_l2;
 		/* ---- stage s2 ---- */
 		const int nw2 = fits ? (l2 + 15) >> 4 : 0;

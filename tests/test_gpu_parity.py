@@ -865,6 +865,20 @@ def test_all_vs_all_mode(al):
                 assert got[t] == (ref["score"], ref["end_i"], ref["end_j"], ref["ops"]), (mode, a, b)
                 t += 1
         assert t == total
+    # edit distance with unit costs over the same triangle: the bit-parallel kernel enumerates the pairs itself (one alignment per lane)
+    al.set_scoring(1, 1, -5, -1)
+    res = torch.zeros((5, total), dtype=torch.int32, device=dev)
+    al.align_allpairs_device(A.MODES["edit"], n, d_words.data_ptr(), bits, d_woff.data_ptr(), d_len.data_ptr(), maxl,
+                             0, total, False, res[0].data_ptr(), res[1].data_ptr(), res[2].data_ptr(), res[3].data_ptr(),
+                             0, 0, res[4].data_ptr(), torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    assert "myers" in al.last_config and "64x1-lane" in al.last_config, al.last_config
+    r = res.cpu().numpy()
+    t = 0
+    for a in range(n):
+        for b in range(a + 1, n):
+            assert (int(r[0, t]), int(r[1, t]), int(r[2, t])) == (O.align(O.EDIT, reads[a], reads[b], 1, 1, -5, -1)["score"], len(reads[a]), len(reads[b])), (a, b)
+            t += 1
 
 
 def test_gpu_rendering_device_entry_full_size(al):

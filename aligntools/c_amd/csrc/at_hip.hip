@@ -918,7 +918,7 @@ static int align_device(at_handle *h, int mode, int64_t npairs,
 		const bool per_lane = max_len1 <= lane_max && max_len1 <= 1024 && myers_windows(64) <= 60 * 1024 &&
 		                      (max_len1 <= 256 || npairs >= env_ll("AT_MYERS_LANE_MIN_PAIRS", 16384)) && env_ll("AT_MYERS_GROUP", 1) == 1;
 		const int g = per_lane ? 1 : max_len1 <= 256 && myers_windows(8) <= 60 * 1024 ? 8 : 32;
-		const int w = per_lane ? (max_len1 <= 160 ? 5 : max_len1 <= 256 ? 8 : max_len1 <= 512 ? 16 : 32)
+		const int w = per_lane ? (max_len1 <= 64 ? 2 : max_len1 <= 96 ? 3 : max_len1 <= 128 ? 4 : max_len1 <= 160 ? 5 : max_len1 <= 256 ? 8 : max_len1 <= 512 ? 16 : 32)
 		            : max_len1 <= 1024 ? 1 : max_len1 <= 2048 ? 2 : max_len1 <= 4096 ? 4 : max_len1 <= 8192 ? 8 : max_len1 <= 16384 ? 16 : 32;
 		at_myers_fn fn = at_pick_myers(w, g);
 		const int per_wave = 64 / g;

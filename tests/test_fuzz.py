@@ -38,8 +38,10 @@ def test_fuzz_campaign_aimed(aim):
             del os.environ[k]
     assert n >= 1500
     keys = " | ".join(seen)
-    for family in (("overlap scores-only int32", "edit int32") if aim.startswith("overlap") else ("myers W5 64x1", "myers W8 64x1", "myers W16 64x1", "myers W32 64x1")):
+    for family in (("overlap scores-only int32", "edit int32") if aim.startswith("overlap") else ("myers W2 64x1", "myers W16 64x1", "myers W32 64x1")):
         assert family in keys, (family, sorted(seen))
+    if not aim.startswith("overlap"):
+        assert sum(1 for k in seen if "myers" in k and "64x1" in k) >= 5, sorted(seen)   # (2, 3, 4, 5, 8, 16, 32 words per lane: most of them)
 
 
 def test_fuzz_campaign_reached_every_kernel_family():

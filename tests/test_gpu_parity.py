@@ -1112,10 +1112,11 @@ def test_bit_parallel_edit_distance(al):
     assert "myers" in al.last_config and "words/lane=32" in al.last_config, al.last_config   # (20 000 rows: 32 lanes x 32 words)
     for k, (a, b) in enumerate(ragged):
         assert int(res["score"][k]) == O.align(O.EDIT, a, b, 1, 1, -5, -1)["score"], (k, len(a), len(b))
-    # reads of up to 256 bases: one alignment per LANE (64 per wavefront), 5 words for up to 160 bases, 8 beyond; a second sequence too
+    # reads of up to 256 bases: one alignment per LANE (64 per wavefront), 2 / 3 / 4 / 5 words for up to 64 / 96 / 128 / 160 bases, 8 beyond; a second sequence too
     # long for 64 windows in LDS keeps the eight-lane groups
     for l1, l2, want, groups in ((150, 150, 5, "64x1-lane"), (160, 90, 5, "64x1-lane"), (161, 300, 8, "64x1-lane"), (256, 256, 8, "64x1-lane"),
-                                 (33, 2000, 5, "64x1-lane"), (40, 4000, 1, "8x8-lane"), (1000, 1000, 1, "2x32-lane"), (1024, 700, 1, "2x32-lane"),
+                                 (33, 2000, 2, "64x1-lane"), (64, 70, 2, "64x1-lane"), (65, 50, 3, "64x1-lane"), (96, 120, 3, "64x1-lane"), (97, 97, 4, "64x1-lane"),
+                                 (128, 200, 4, "64x1-lane"), (129, 129, 5, "64x1-lane"), (40, 4000, 1, "8x8-lane"), (1000, 1000, 1, "2x32-lane"), (1024, 700, 1, "2x32-lane"),
                                  (1025, 1100, 2, "2x32-lane")):
         uniform = [(dna(l1), dna(l2)) if k % 2 else (lambda a: (a, (related(a) + dna(l2))[:l2]))(dna(l1)) for k in range(70 if l1 > 256 else 200)]
         res = al.align_batch("edit", uniform)

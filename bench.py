@@ -613,7 +613,7 @@ def main():
                       else "GCUPS (DP cell updates/s), %s %dx%d" % (mode, l1, l2),
             "value": gcups, "unit": "GCUPS", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "strong" if full_triangle else "weak",
-            "vs_baseline": None, "dtype": "int16" if "packed16" in al.last_config else "int32", "data": "synthetic",
+            "vs_baseline": None, "dtype": "int16" if "packed16" in al.last_config else "u32" if al.last_config.startswith("myers") else "int32", "data": "synthetic",
             "config": {"workload": "%s: %s %s, %d x (%dx%d bp) pairs per GPU, uniform ACGT, m=%d u=%d o=%d e=%d%s, "
                                    "%s" % (args.workload, mode, "linear-gap" if mode == "overlap" else "unit-gap" if mode == "edit" else "affine-gap", pairs, l1, l2,
                                            m, u, o, e, " j=%d -s" % j if uj else "",

@@ -808,7 +808,7 @@ static int align_device(at_handle *h, int mode, int64_t npairs,
 	if ((uniform_shape || rag) && ap_n == 0) {
 		if (packed_ok(h, mode, bits, max_len1, max_len2, 4, &thresh16)) ts = 4;
 		else if ((!rag || kmode == at::K_OVERLAP) && packed_ok(h, mode, bits, max_len1, max_len2, 2, &thresh16)) ts = 2;
-		/* overlap: the packed kernel exists with pointers only (scores alone: the int32 kernel's 3 instructions per cell win) */
+		/* overlap: the packed kernel exists with pointers only (scores alone: the int32 kernel's 2 instructions per cell win) */
 		if (kmode == at::K_OVERLAP && (!tb || getenv("AT_NO_PACKED_OVERLAP"))) ts = 0;
 	}
 	if (rag && (!ts || (kmode > at::K_FITJ && !(kmode == at::K_OVERLAP && rag == 64)) || max_len1 > (rag == 8 ? 152 : rag == 16 ? 304 : rag == 32 ? 608 : 1024) || !d_order))

@@ -4,19 +4,23 @@
  * D(i,j) = min3(D(i,j-1) + 1, D(i-1,j-1) + (s1[i-1] == s2[j-1] ? 0 : u), D(i-1,j) + 1), returns D(l1,l2).
  * With the mismatch cost u == 1 (`edit -u 1`) this is the Levenshtein distance, and the column of vertical
  * differences D(i,j) - D(i-1,j) in {-1,0,+1} fits two bit vectors (Myers 1999, block form of Hyyro 2003):
- * one 32-bit word holds 32 rows, a column step costs ~17 word operations per word instead of 32 cells.
+ * one 32-bit word holds 32 rows, a column step costs 14 instructions per word (below) instead of 32 cells.
  * Any other u keeps the cell-by-cell kernel (at_sweep.hip.h, K_EDIT): a negative u, the reference's
  * default, is not a distance and has no such encoding.
  *
- * Mapping: G lanes per alignment (G = 32: two alignments per wavefront, l1 <= 1024 * W; G = 8: eight alignments of
- * reads up to 256 bases; G = 1 (round 3): ONE ALIGNMENT PER LANE, 64 per wavefront, W = 5 or 8 words for reads of up to 160 / 256
- * bases -- no skew, no idle lanes, a column step of W chained word steps per lane: 230 instead of 965 instructions per alignment
- * of 150 x 150; each alignment with its own lengths), W consecutive words (32*W rows) per lane, the words of
- * a column chained through the horizontal difference (hin/hout).
- * Like the sweep kernels the lanes are skewed: lane l works on column t - l at step t and takes the
- * horizontal difference of the word above from lane l-1's previous step by one DPP move.  The first word's
- * hin is +1 (the border D(0,j) = j).  The lane that holds row l1 adds its horizontal differences up:
- * D(l1,j) = l1 + sum.  s2 is staged in LDS as packed 2-bit words.
+ * Mapping: G lanes per alignment, W consecutive words (32 * W rows) per lane, the words of a column chained through the
+ * horizontal difference (the word above's Ph / Mh), every alignment with its own lengths.
+ *   G = 1 (round 3): ONE ALIGNMENT PER LANE, 64 per wavefront, W = 2 / 3 / 4 / 5 / 8 / 16 / 32 words for reads of up to 64 / 96 / 128 /
+ *          160 / 256 / 512 / 1 024 bases -- no skew, no idle lanes, a column step is W chained word steps inside the lane; the 64 s2
+ *          windows of a wavefront in LDS (odd stride), one LDS word per sixteen columns;
+ *   G = 32: two alignments per wavefront, l1 <= 1 024 * W with W up to 32 (32 768 bases); G = 8: eight alignments of reads up to 256
+ *          bases (the round-2 form, kept for A/B runs and for second sequences too long for 64 LDS windows).  Like in the sweep
+ *          kernels the lanes are skewed: lane l works on column t - l at step t and takes the horizontal-difference words of the word
+ *          above from lane l - 1's previous step by one DPP move each.
+ * The first word's horizontal input is +1 (the border D(0,j) = j).  When a lane has passed its last column its Pv / Mv are the vertical
+ * differences of column l2: D(l1, l2) = l2 + popcount(Pv & rows <= l1) - popcount(Mv & rows <= l1), summed over the alignment's words
+ * and lanes once.  s2 is staged in LDS as packed 2-bit words.  All-vs-all over one read set: the pairs of the triangle are enumerated
+ * here (ap_n / ap_first), like in at_sweep.
  */
 #pragma once
 #include "at_sweep.hip.h"

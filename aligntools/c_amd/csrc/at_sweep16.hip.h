@@ -223,7 +223,7 @@ AT_DEV long long sweep16_items(const Sweep16Args &a, long long wnext, const long
 	 * M(i-1,j) + o), first wins in that order -> tags LEFT 3 / DIAGONAL 2 / RIGHT 1 on the three candidates (the diagonal
 	 * one through the score LUT), the winner's tag is the cell's pointer.  Xl holds the row's clean M of the previous
 	 * column (left neighbour, and diagonal input of the row below); 9.25 instructions per row-step with pointers.  Only
-	 * built with pointers: without them the int32 kernel's three instructions per cell (SDWA add, v_max3_i32, add) win. */
+	 * built with pointers: without them the int32 kernel's two instructions per cell (SDWA add, v_max3_i32: the sweep on the gap ramp, at_sweep.hip.h) win. */
 	constexpr bool OVL = MODE == K_OVERLAP;
 	static_assert(!OVL || (TB && TS == 2), "packed overlap: scores x4 with 2-bit tags, tracebacks");
 	constexpr bool HASJ = MODE == K_FITJ;

@@ -138,6 +138,13 @@ static int fail(at_handle *h, int code, const char *fmt, ...)
 
 extern "C" const char *at_last_error(const at_handle *h) { return h ? h->err : g_err; }
 extern "C" const char *at_last_config(const at_handle *h) { return h ? h->cfg : "none"; }
+/* diagnostic builds (-DAT_TP_STATS=1): the 8 words of the handle's work counter block, after a device synchronisation */
+extern "C" int at_debug_counters(at_handle *h, unsigned long long *out8)
+{
+	if (!h || !out8 || !h->d_queue) return AT_ERR_ARG;
+	if (hipDeviceSynchronize() != hipSuccess) return AT_ERR_NODEVICE;
+	return hipMemcpy(out8, h->d_queue, 64, hipMemcpyDeviceToHost) == hipSuccess ? AT_OK : AT_ERR_NODEVICE;
+}
 
 extern "C" int at_init(const int *device_ids, int n_devices, at_handle **out)
 {
@@ -396,7 +403,7 @@ struct Layout16 {
  * lanes (8 alignments per wave, 85 %; one group of 64 lanes: 59 %) and so do 209..304 bases with 16 / 19 rows per lane,
  * 305..608 bases as 2 groups of 32 lanes (10 .. 19 rows per lane), everything
  * else as one group of 64 lanes.  AT_GROUP = 8 / 16 / 32 / 64 caps the choice (A/B runs); ragged frames name their group width themselves. */
-static Layout16 layout16_for(bool tb, bool hasj, int l1, int l2, int ts, int force_g = 0, bool overlap = false, int kmode = -1, int force_k = 0)   /* force_g: 8 / 16 = ragged frames on that group width; 64 = the 64-lane items behind a batch of narrow-group items, force_k rows per lane */
+static Layout16 layout16_for(bool tb, bool hasj, int l1, int l2, int ts, int force_g = 0, bool overlap = false, int kmode = -1, int force_k = 0, bool two_pass = false)   /* force_g: 8 / 16 = ragged frames on that group width; 64 = the 64-lane items behind a batch of narrow-group items, force_k rows per lane */
 {
 	Layout16 L;
 	const long long g_forced = env_ll("AT_GROUP", 0);
@@ -404,7 +411,7 @@ static Layout16 layout16_for(bool tb, bool hasj, int l1, int l2, int ts, int for
 	L.k = rows_per_lane(l1);
 	/* scores only, scores x4: 16 rows per lane (strips of 1 024 rows) once that is fewer lane-steps than strips of 256 --
 	 * per step a lane does 16 x 11 + 25 instructions instead of 4 x 11 + 25 */
-	if (!tb && ts == 2 && !getenv("AT_ROWS_PER_LANE") && ((l1 + 1023) / 1024) * (16 * 11 + 25) < ((l1 + 255) / 256) * (4 * 11 + 25)) L.k = 16;
+	if (!tb && (ts == 2 || two_pass) && !getenv("AT_ROWS_PER_LANE") && ((l1 + 1023) / 1024) * (16 * 11 + 25) < ((l1 + 255) / 256) * (4 * 11 + 25)) L.k = 16;
 	/* overlap (one state: few registers even with pointers): 4 or 16 rows per lane, whichever needs fewer instructions */
 	if (overlap) L.k = env_ll("AT_ROWS_PER_LANE", 0) == 4 ? 4 : ((l1 + 1023) / 1024) * (16 * 9 + 45) < ((l1 + 255) / 256) * (4 * 9 + 30) ? 16 : 4;
 	if (force_g == 64) {
@@ -448,7 +455,10 @@ static Layout16 layout16_for(bool tb, bool hasj, int l1, int l2, int ts, int for
 	const long long nstrips = (l1 + L.g * L.k - 1) / (L.g * L.k);
 	long long nref = (at::kPad + (long long)tbk * blk) / 4 + 4;
 	nref = (nref + 1) & ~1LL;
-	const long long nbound = 2LL * (l2 + 2);
+	/* (two-pass tracebacks: the boundary row's words double as the replay's staging area and the walkers' tile cache) */
+	/* (... the replay's rows above, CK + 1 entries of two words per lane; then every walker's copy of the block it walks) */
+	const long long walk_words = ((L.k + 3) / 4 + (hasj ? ((L.k + 3) / 4 + 3) / 4 : 0)) * (long long)AT_CK_STEPS;
+	const long long nbound = std::max<long long>(2LL * (l2 + 2), two_pass ? std::max<long long>(at::ck_stage_words(AT_CK_STEPS), 2 * ng * walk_words * (L.g == 64 ? 4 : 1)) : 0);
 	/* steps per pointer word (and alignment): 4-bit cells, 4; the jump state with scores x4 keeps byte cells, 2 -- with scores x16 it has
 	 * 4-bit cells plus a bit plane of one word per 4 rows x 4 steps behind the cells (at_sweep16.hip.h: JPL); packed overlap: 2-bit cells, 8 */
 	const int spw = overlap ? 16 / AT_OVL_BITS : (hasj && !(ts == 4 && AT_JPLANE)) ? 2 : 4;
@@ -500,6 +510,29 @@ static bool packed_ok(const at_handle *h, int mode, int bits, int l1, int l2, in
 	if (scale * (lo + hi + slack) >= 32768) return false;
 	*thresh16 = (int)(-32768 + scale * (hi + slack));
 	return true;
+}
+
+/* Two-pass tracebacks (at_sweep16.hip.h, CK kernels): the regions of a wave's global slot -- border row, row checkpoints, column
+ * checkpoints, the replayed blocks' pointer words and jump plane -- for the scores-only layout L of the sweep */
+struct TpLayout {
+	int off_brow, off_rck, off_cck, off_rptr, off_rjpl;
+	long long words;
+};
+static TpLayout tp_layout(const Layout16 &L, int kmode, int l2)
+{
+	const int blk = L.g <= 16 ? 4 : 8, cb = AT_CK_STEPS;
+	const long long T = (long long)((l2 + L.g - 1 + blk - 1) / blk) * blk;   /* steps of a sweep */
+	const int es = kmode == at::K_FITJ ? 4 : 3, nq = ((kmode == at::K_FITJ ? 3 : 2) * L.k + 3) / 4, kg = (L.k + 3) / 4;
+	auto up4 = [](long long v) { return (v + 3) & ~3LL; };
+	TpLayout t;
+	long long w = 0;
+	t.off_brow = (int)w; w = up4(w + (T + cb + 2) * es);
+	t.off_rck = (int)w; w = up4(w + (T + cb + 2) * 64 * es);
+	t.off_cck = (int)w; w = up4(w + (T / cb + 3) * nq * 256);
+	t.off_rptr = (int)w; w = up4(w + (cb / 4) * ((L.k + 3) / 4) * 256);   /* [4 steps][4 rows][lane][row in group] */
+	t.off_rjpl = (int)w; w = up4(w + (cb / 4) * ((kg + 3) / 4) * 256);
+	t.words = w;
+	return t;
 }
 
 static int choose_store(long long words_fixed, long long words_ptr, bool prefer_hbm_pointers);
@@ -630,7 +663,7 @@ static int plan_launch(at_handle *h, const char *tag, int k, long long nwork, lo
 		pl->ws = h->d_ws;
 	}
 	pl->grid = grid;
-	if (!h->d_queue) HIP_TRY(h, hipMalloc((void **)&h->d_queue, 64));
+	if (!h->d_queue) { HIP_TRY(h, hipMalloc((void **)&h->d_queue, 64)); HIP_TRY(h, hipMemset(h->d_queue, 0, 64)); }
 	HIP_TRY(h, hipMemsetAsync(h->d_queue, 0, 8, stream));
 	static const char *names[3] = {"lds", "lds+hbm-pointers", "hbm"};
 	snprintf(h->cfg, sizeof h->cfg, "%s store=%s rows/lane=%d lds=%zuB slot=%lldB waves/cu<=%lld grid=%lld", tag, names[store], k,
@@ -831,6 +864,20 @@ static int align_device(at_handle *h, int mode, int64_t npairs,
 			ts = 0;
 		}
 	}
+	/* two-pass tracebacks: uniform batches whose shape has a CK kernel sweep without pointers and rebuild them where the walks go.
+	 * By default where that wins -- the 64-lane groups with 16 rows per lane (reads of 609 .. 1 024 bases: the one-pass kernels hold 4 rows
+	 * per lane there and need four strips); AT_TWO_PASS=2: wherever a CK kernel exists (the 8-lane groups x 19 rows lose: C2 -7 %, C4
+	 * -28 %, profiles/r04/two_pass_ab.txt), AT_TWO_PASS=0: never (A/B runs) */
+	bool two_pass = false;
+	const long long tp_mode = env_ll("AT_TWO_PASS", 1);
+	if (ts && tb && !rag && kmode <= at::K_FITJ && tp_mode) {
+		const Layout16 P2 = layout16_for(false, kmode == at::K_FITJ, max_len1, max_len2, ts, 0, false, kmode, 0, true);
+		if ((P2.g == 64 || tp_mode == 2) && (long long)P2.g * P2.k >= max_len1 && at_pick16_tp(kmode, P2.g, P2.k, ts, bits) &&
+		    choose_store(P2.off_ptr, 1, true) == 1) {
+			two_pass = true;
+			P = P2;
+		}
+	}
 	if (ts) {
 		Sweep16Args b;
 		memset(&b, 0, sizeof b);
@@ -855,7 +902,11 @@ static int align_device(at_handle *h, int mode, int64_t npairs,
 		char tag16[112];
 		snprintf(tag16, sizeof tag16, "packed16 x%d bits=%d %dx%d-lane groups (%d pairs/wave)%s", 1 << ts, bits, 64 / P.g, P.g, per_wave,
 		         rag ? " ragged frames" : "");
-		auto pick = [&](int st) { return rag ? at_pick16_rag(kmode, P.g, P.k, st, tb, bits) : at_pick16(kmode, P.g, P.k, ts, st, tb, bits); };
+		if (two_pass) snprintf(tag16 + strlen(tag16), sizeof tag16 - strlen(tag16), " two-pass ck=%d", AT_CK_STEPS);
+		auto pick = [&](int st) {
+			if (two_pass) return st == 1 ? at_pick16_tp(kmode, P.g, P.k, ts, bits) : (at_sweep16_fn) nullptr;
+			return rag ? at_pick16_rag(kmode, P.g, P.k, st, tb, bits) : at_pick16(kmode, P.g, P.k, ts, st, tb, bits);
+		};
 		const long long nwork = (npairs + per_wave - 1) / per_wave;
 		/* The grid is the resident waves, each pulling work items until none are left.  A SIMD holds two of these waves and finishes
 		 * an item every ~118 us: C2's 6 250 items of 16 pairs on 1 024 SIMDs are 6.1 items per SIMD, so a launch that has the chip to
@@ -867,10 +918,13 @@ static int align_device(at_handle *h, int mode, int64_t npairs,
 		 * main launch: +6.5 % alone, -8 % in flight -- the next batch's waves took the slots the sliver was waiting for.) */
 		const bool tail_ok = !rag && !only_if && P.g <= 16 && kmode != at::K_OVERLAP && env_ll("AT_TAIL_SPLIT", 1);
 		Layout16 PT = P;
-		if (tail_ok) PT = layout16_for(tb, kmode == at::K_FITJ, max_len1, max_len2, ts, at::AT_TAIL_G, false, kmode, at::at_tail_k(P.g, P.k));
+		if (tail_ok) PT = layout16_for(tb && !two_pass, kmode == at::K_FITJ, max_len1, max_len2, ts, at::AT_TAIL_G, false, kmode, at::at_tail_k(P.g, P.k), two_pass);
+		TpLayout tpm = {0, 0, 0, 0, 0, 0}, tpt = tpm;
+		if (two_pass) { tpm = tp_layout(P, kmode, max_len2); tpt = tp_layout(PT, kmode, max_len2); }
 		/* (the sliver's items use the main items' LDS window and pointer slot: both hold either layout -- the main items' are the larger) */
-		int rc = plan_launch(h, tag16, P.k, nwork, std::max(P.off_ptr, PT.off_ptr), std::max(P.words - P.off_ptr, PT.words - PT.off_ptr), &pl, stream,
-		                     [&](int st) { return (const void *)pick(st); }, P.g < 64 || rag);
+		int rc = plan_launch(h, tag16, P.k, nwork, std::max(P.off_ptr, PT.off_ptr),
+		                     two_pass ? std::max(tpm.words, tpt.words) : std::max(P.words - P.off_ptr, PT.words - PT.off_ptr), &pl, stream,
+		                     [&](int st) { return (const void *)pick(st); }, P.g < 64 || rag || two_pass);
 		if (rc) return rc;
 		int64_t n_tail = 0;
 		if (tail_ok && nwork > pl.grid) {
@@ -894,6 +948,11 @@ static int align_device(at_handle *h, int mode, int64_t npairs,
 		}
 		b.off_ptr = pl.off_ptr; b.ws = pl.ws; b.ws_slot_words = pl.slot_words; b.queue = h->d_queue;
 		bt.off_ptr = pl.store == 1 ? 0 : PT.off_ptr; bt.ws = pl.ws; bt.ws_slot_words = pl.slot_words; bt.queue = h->d_queue;
+		if (two_pass) {
+			if (pl.store != 1) return fail(h, AT_ERR_RANGE, "two-pass tracebacks need the s2 windows in LDS (store=%d)", pl.store);
+			b.off_brow = tpm.off_brow; b.off_rck = tpm.off_rck; b.off_cck = tpm.off_cck; b.off_rptr = tpm.off_rptr; b.off_rjpl = tpm.off_rjpl;
+			bt.off_brow = tpt.off_brow; bt.off_rck = tpt.off_rck; bt.off_cck = tpt.off_cck; bt.off_rptr = tpt.off_rptr; bt.off_rjpl = tpt.off_rjpl;
+		}
 		at_sweep16_fn fn16 = pick(pl.store);
 		if (!fn16 || (P.g != 64 && pl.store == 2)) return fail(h, AT_ERR_RANGE, "no packed kernel for this shape (rows/lane=%d, store=%d)", P.k, pl.store);
 		if (pl.dyn_lds > 48 * 1024)

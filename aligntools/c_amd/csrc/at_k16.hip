@@ -14,7 +14,9 @@
 	at_sweep16_fn at_pick16_rag16_b##b(int kmode, int k, int store, bool tb);      \
 	at_sweep16_fn at_pick16_rag16b_b##b(int kmode, int k, int store, bool tb);     \
 	at_sweep16_fn at_pick16_rag32_b##b(int kmode, int k, int store, bool tb);      \
-	at_sweep16_fn at_pick16_ragovl_b##b(int k, int store);
+	at_sweep16_fn at_pick16_ragovl_b##b(int k, int store);                           \
+	at_sweep16_fn at_pick16_tp8_b##b(int kmode, int k);                              \
+	at_sweep16_fn at_pick16_tp64_b##b(int kmode, int k, int ts);
 AT_DECL(2)
 AT_DECL(8)
 #undef AT_DECL
@@ -43,4 +45,11 @@ at_sweep16_fn at_pick16_rag(int kmode, int g, int k, int store, bool tb, int bit
 	if (k >= 16) return bits == 8 ? at_pick16_rag16b_b8(kmode, k, store, tb) : at_pick16_rag16b_b2(kmode, k, store, tb);   /* reads of 209..304 bases */
 	if (kmode == at::K_LOCAL) return bits == 8 ? at_pick16_rag_impl_b8(k, store, tb) : at_pick16_rag_impl_b2(k, store, tb);
 	return bits == 8 ? at_pick16_rag16_b8(kmode, k, store, tb) : at_pick16_rag16_b2(kmode, k, store, tb);
+}
+/* two-pass traceback kernels (CK): global slot for the checkpoints, LDS for the s2 windows */
+at_sweep16_fn at_pick16_tp(int kmode, int g, int k, int ts, int bits)
+{
+	if (g == 8) return ts != 4 ? nullptr : bits == 8 ? at_pick16_tp8_b8(kmode, k) : at_pick16_tp8_b2(kmode, k);
+	if (g == 64) return bits == 8 ? at_pick16_tp64_b8(kmode, k, ts) : at_pick16_tp64_b2(kmode, k, ts);
+	return nullptr;
 }

@@ -1,0 +1,20 @@
+#include "at_launch.h"
+/* two-pass traceback kernels (at_sweep16.hip.h, CK): the scores-only sweep with checkpoints, pointers rebuilt block by block where the
+ * walks need them.  This unit: eight groups of 8 lanes x 19 rows (reads of 129 .. 152 bases: C2, C4), scores x16 */
+template <int MODE>
+static at_sweep16_fn tp8(int k)
+{
+	switch (k) {
+	case 19: return at::at_sweep16<MODE, 8, 19, 4, true, false, false, false, AT_BITS16, AT_CK_STEPS>;
+	default: return nullptr;
+	}
+}
+at_sweep16_fn AT_NAME(at_pick16_tp8)(int kmode, int k)
+{
+	switch (kmode) {
+	case at::K_GLOBAL: return tp8<at::K_GLOBAL>(k);
+	case at::K_LOCAL: return tp8<at::K_LOCAL>(k);
+	case at::K_FITJ: return tp8<at::K_FITJ>(k);
+	default: return tp8<at::K_FIT>(k);
+	}
+}

@@ -14,6 +14,7 @@ at_sweep_fn at_pick32_b2(int kmode, int k, int store, bool tb);
 at_sweep_fn at_pick32_b8(int kmode, int k, int store, bool tb);
 at_sweep16_fn at_pick16_rag(int kmode, int g, int k, int store, bool tb, int bits);   /* ragged frames: g in {8, 16} */
 at_sweep16_fn at_pick16(int kmode, int g, int k, int ts, int store, bool tb, int bits);
+at_sweep16_fn at_pick16_tp(int kmode, int g, int k, int ts, int bits);   /* two-pass tracebacks (CK kernels), or nullptr */
 /* every packed translation unit is compiled twice: -DAT_BITS16=2 (16 codes per sequence word, score LUT) and
  * -DAT_BITS16=8 (4 bytes per word, compare); its entry points carry the suffix _b2 / _b8 */
 #ifndef AT_BITS16

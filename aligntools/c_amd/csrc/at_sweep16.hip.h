@@ -34,6 +34,7 @@
  */
 #pragma once
 #include "at_sweep.hip.h"
+#include <utility>
 
 #ifndef AT_WALK_AHEAD
 #define AT_WALK_AHEAD 4   /* fit walks: pointer words loaded ahead along the current run (C4: 2 -> 1.96, 4 -> 2.07, 8 -> 2.01 TCUPS) */
@@ -91,6 +92,9 @@ struct Sweep16Args {
 	const int *order;
 	const int *only_if;            /* optional guard, see SweepArgs */
 	int only_val;
+	/* two-pass tracebacks (CK kernels, see replay16_block): regions of the per-wave global slot, word offsets --
+	 * border row 0, row checkpoints, column checkpoints, the replayed blocks' pointer words (+ jump plane) */
+	int off_brow, off_rck, off_cck, off_rptr, off_rjpl;
 };
 
 AT_DEV uint32_t pk2(int v) { return ((uint32_t)v & 0xffffu) | ((uint32_t)v << 16); }
@@ -211,11 +215,379 @@ AT_DEV int pidx(int wr, int r, int lane, int NL)
 	else return r < KF ? __mul24(wr, NL * K) + __mul24(r & ~3, NL) + lane * 4 + (r & 3) : __mul24(wr, NL * K) + KF * NL + lane * KR + (r - KF);
 }
 
+/* ======================================================================================================================
+ * Two-pass tracebacks (round 4; CK kernels).
+ *
+ * The forward sweep of a CK kernel is the scores-only sweep (no priority tags, no pointer words: a third of the
+ * instructions of a row-step less) plus CHECKPOINTS in the wave's global slot:
+ *   row checkpoints     every lane, every step: (L, M, U[, J]) of its LAST row, both alignments packed -- what the lane
+ *                       below needs of the row above it.  Entry e = t + 1 is the state after step t, entry 0 the border.
+ *   column checkpoints  every lane, every CB steps: (M + o, U[, J]) of its K rows -- what a lane needs of its own past.
+ * The traceback then runs in ROUNDS.  A block is (lane band, CB steps of that lane): K rows x CB columns.  In a round
+ * every lane replays two blocks, one per 16-bit half, each for the alignment of that half of its group, on its own:
+ * the cell above comes from the row checkpoint instead of a DPP move, so nothing ties the lanes (or the halves)
+ * together and G lanes give every alignment G blocks per round -- laid out along the direction its walk is taking
+ * (CkPattern).  The replay is the tagged arithmetic of the one-pass kernels (same first-wins order, same pointer
+ * cells), its pointer words go to a small region of the slot, and the alignment's walker consumes them until it leaves
+ * the blocks of the round.  Pointers depend on nothing but the exact boundary values, so the ops are those of the
+ * one-pass kernels (trace_back_gla / _local_affine / _fit_affine_jump, alignment.h:372-412, 558-592, 766-800).
+ * ====================================================================================================================== */
+#ifndef AT_TP_STATS
+#define AT_TP_STATS 0     /* 1: throw-away build that counts rounds / items / walk ops / cycles in the words behind the work counter */
+#endif
+#ifndef AT_TP_ONEBODY
+#define AT_TP_ONEBODY 1
+#endif
+#ifndef AT_CK_STEPS
+#define AT_CK_STEPS 16    /* CB: steps between two column checkpoints = columns of a replayed block */
+#endif
+template <int MODE> constexpr int ck_es() { return MODE == K_FITJ ? 4 : 3; }                     /* words of a row checkpoint entry */
+template <int MODE, int K> constexpr int ck_nq() { return ((MODE == K_FITJ ? 3 : 2) * K + 3) / 4; }   /* 16-byte chunks of a column checkpoint */
+constexpr int ck_log2(int v) { return v <= 1 ? 0 : 1 + ck_log2(v / 2); }
+
+/* Which blocks a round replays for one alignment, seen from its walker's cell (ci, cj) -- the anchor.  Band b = the lane
+ * that owns row ci, t = (cj - 1) + band = the step at which that lane swept column cj, t-block c = t / CB.
+ *   diagonal: the walk is in M or L -- it climbs.  Along the diagonal ray from the anchor band b - dr is crossed at steps
+ *             t_hi(dr) = T0 - rho0 - 2 - (dr - 1)(K + 1) down to t_hi - (K - 1); W t-blocks per band around that, G / W bands.
+ *   horizontal: the walk is in U or J -- it runs left along its row: the G t-blocks of band b from the anchor's downwards. */
+template <int G, int K, int CB>
+struct CkPattern {
+	static constexpr int LCB = ck_log2(CB);
+	/* one group of 64 lanes: W = 3 t-blocks around the ray in each of 21 bands (closed forms: a walk of a thousand ops looks its
+	 * blocks up a hundred times).  Narrower groups have 4 .. 32 slots and spend them exactly: band by band the t-blocks the ray
+	 * crosses, MU / ML steps of margin above / below it (an L op moves a walk above the ray, a U op below). */
+	static constexpr bool FIXED = G == 64;
+	static constexpr int W = 3, NB = G / W;
+	static constexpr int MHr = (W * CB - K) / 2, MH = MHr < 0 ? 0 : MHr > CB ? CB : MHr;
+	static constexpr int MU = 3, ML = 3;
+	int b, c0, thi1, horiz;
+	AT_DEV void set(int ci, int cj, bool hz)
+	{
+		b = (ci - 1) / K;
+		const int rho = (ci - 1) - b * K, T0 = cj - 1 + b;
+		c0 = T0 >> LCB; thi1 = T0 - rho - 2; horiz = hz ? 1 : 0;
+	}
+	AT_DEV int ctop(int dr) const { return dr == 0 ? c0 : (thi1 - (dr - 1) * (K + 1) + MH) >> LCB; }   /* (arithmetic shift: floor) */
+	/* band b - dr holds the t-blocks chi, chi - 1, ... chi - n + 1 of this round */
+	AT_DEV void band(int dr, int &chi, int &n) const
+	{
+		if constexpr (FIXED) { chi = ctop(dr); n = W; }
+		else {
+			const int thi = thi1 - (dr - 1) * (K + 1);                     /* (dr = 0: the ray starts at the anchor's own step, c0) */
+			const int tlo = dr == 0 ? thi1 + 2 : thi - (K - 1);
+			chi = dr == 0 ? c0 : (thi + MU) >> LCB;
+			const int clo = imax((tlo - ML) >> LCB, 0);
+			n = imax(chi - clo + 1, 0);
+		}
+	}
+	AT_DEV void block(int q, int T, int &bl, int &c, bool &valid) const   /* T: steps of the sweep */
+	{
+		bl = -1; c = 0;
+		if (horiz) { bl = b; c = c0 - q; }
+		else if constexpr (FIXED) { const int dr = q / W; if (dr < NB) { bl = b - dr; c = ctop(dr) - q % W; } }
+		else {
+			int ql = q;
+			for (int dr = 0; dr <= b; ++dr) {
+				int chi, n;
+				band(dr, chi, n);
+				if (ql < n) { bl = b - dr; c = chi - ql; break; }
+				ql -= n;
+			}
+		}
+		valid = bl >= 0 && c >= 0 && c * CB < T && (c + 1) * CB > bl;   /* (the block holds a step at which its lane is inside the matrix) */
+	}
+	/* the slot that holds block (bl, c) this round, or -1 */
+	AT_DEV int slot(int bl, int c) const
+	{
+		const int dr = b - bl;
+		if (horiz) { const int w = c0 - c; return dr == 0 && w >= 0 && w < G ? w : -1; }
+		if constexpr (FIXED) {
+			if (dr < 0 || dr >= NB) return -1;
+			const int w = ctop(dr) - c;
+			return w >= 0 && w < W ? dr * W + w : -1;
+		} else {
+			if (dr < 0) return -1;
+			int chi, n, s0 = 0;
+			for (int d = 0; d < dr; ++d) { band(d, chi, n); s0 += n; if (s0 >= G) return -1; }
+			band(dr, chi, n);
+			const int w = chi - c;
+			return w >= 0 && w < n && s0 + w < G ? s0 + w : -1;
+		}
+	}
+};
+
+template <typename F, int... Q>
+AT_DEV void static_for_impl(F &f, std::integer_sequence<int, Q...>) { (f(std::integral_constant<int, Q>{}), ...); }
+template <int N, typename F>
+AT_DEV void static_for(F &f) { static_for_impl(f, std::make_integer_sequence<int, N>{}); }
+
+/* Word (s4, r, lane) of a round's replayed pointer words: s4 = group of 4 steps of the block, r = row in lane; four rows of a lane
+ * adjacent (the rows padded to a multiple of 4), so that a lane stores 16 bytes at once and a walk fetches a tile of 4 rows x 4
+ * steps with one load.  KQ = 16-byte groups per s4. */
+template <int KQ>
+AT_DEV int ridx(int s4, int r, int lane) { return (s4 * KQ + (r >> 2)) * 256 + lane * 4 + (r & 3); }
+constexpr int ck_stage_words(int cb) { return 64 * (cb + 1) * 2; }   /* LDS: the row above the block, step by step, as the lane below sees it */
+/* LDS words of one walker: the pointer words of the block it walks (K rows padded to 4 x CB steps / 4) and the jump plane's */
+template <int G> constexpr int ck_walk_blocks() { return G == 64 ? 4 : 1; }   /* blocks a walker holds in LDS at a time */
+template <int MODE, int K, int CB>
+constexpr int ck_walk_words() { return (K + 3) / 4 * CB + (MODE == K_FITJ ? ((K + 3) / 4 + 3) / 4 * CB : 0); }
+
+AT_DEV uint32_t pk2h(int lo, int hi) { return ((uint32_t)lo & 0xffffu) | ((uint32_t)hi << 16); }
+AT_DEV uint32_t lohi(uint32_t lo, uint32_t hi)   /* low half of `lo`, high half of `hi` */
+{
+	return __builtin_amdgcn_perm(hi, lo, 0x07060100u);
+}
+struct ck_u3 { uint32_t x, y, z; };
+
+/* One round's replay: this lane's two blocks -- (blA, cA) of the alignment in the low halves, (blB, cB) of the one in the
+ * high halves; band = lane-in-group of the forward sweep, c = t-block -- swept with tags from their checkpoints, pointer
+ * words (4-bit cells [+ the jump plane]) to the slot's replay region at [step / 4][row][this lane].  A block starts at
+ * step org = max(c * CB, band) -- a lane's first step inside the matrix is t = band, where its state is the border's --
+ * and runs CB steps; the cell of step t sits at s = t - org.  Steps behind column l2 and rows behind l1 compute cells
+ * nobody reads, as in the forward sweep. */
+#ifndef AT_REPLAY_INLINE
+#define AT_REPLAY_INLINE 1    /* 0: the replay as a function call (A/B: C2 1 943 against 2 120 GCUPS inlined, on the first version) */
+#endif
+#if AT_REPLAY_INLINE
+#define AT_REPLAY_FN AT_DEV
+#else
+#define AT_REPLAY_FN __device__ __noinline__
+#endif
+template <int MODE, int G, int K, int TS, bool SMALL, int BITS, int CB>
+AT_REPLAY_FN void replay16_block(const Sweep16Args &a, const Slot<SMALL> &mem, uint32_t *gs, const int refoff,
+                           const uint32_t *qA, const uint32_t *qB, const int l1A, const int l1B,
+                           const int blA, const int cA, const int blB, const int cB)
+{
+	constexpr bool HASJ = MODE == K_FITJ;
+	static_assert(!HASJ || (TS == 4 && AT_JPLANE), "two-pass jump state: scores x16, 4-bit cells + bit plane");
+	static_assert(MODE == K_GLOBAL || MODE == K_LOCAL || MODE == K_FIT || MODE == K_FITJ, "two-pass tracebacks: the affine modes");
+	static_assert(CB % 4 == 0, "pointer words hold 4 steps");
+	constexpr int TMASK = (1 << TS) - 1;
+	constexpr int TGL = TS == 4 ? 15 : 3, TGM = TS == 4 ? 10 : 2, TGU = 1;
+	constexpr int KG = (K + 3) / 4, ES = ck_es<MODE>(), NQ = ck_nq<MODE, K>();
+	constexpr int PADW = kPad / 4;
+	(void)PADW;
+	const int lane = threadIdx.x, grp = lane / G;
+	const int o16 = a.o16, e16 = a.e16;
+	uint32_t o2 = pk2(o16), e2 = pk2(e16);
+	uint32_t lut_lo = ((uint32_t)a.m16 & 0xffu) | (((uint32_t)a.u16 & 0xffu) * 0x01010100u);
+	uint32_t lut_hi = (((uint32_t)a.m16 >> 8) & 0xffu) | ((((uint32_t)a.u16 >> 8) & 0xffu) * 0x01010100u);
+	uint32_t cClean = (uint32_t)(0xffff & ~TMASK) * 0x00010001u, cTagM = (uint32_t)TGM * 0x00010001u;
+	uint32_t cTagL = (uint32_t)TGL * 0x00010001u, cTagU = (uint32_t)TGU * 0x00010001u;
+	uint32_t cM3 = 0x00030003u, cM7 = 0x00070007u, cF0 = 0x00f000f0u, cF000 = 0xf000f000u, c8888 = 0x88888888u;
+	uint32_t gmo2 = pk2(a.g16 - a.o16), neg2 = 0x80008000u;
+	uint32_t c1 = 0x00010001u, umm2 = pk2(a.u16 - a.m16), m2 = pk2(a.m16);
+	asm volatile("" : "+v"(c8888), "+v"(gmo2), "+v"(neg2), "+v"(c1), "+v"(umm2), "+v"(m2));
+	asm volatile("" : "+v"(o2), "+v"(e2), "+v"(lut_lo), "+v"(lut_hi));
+	asm volatile("" : "+v"(cClean), "+v"(cTagM), "+v"(cTagL), "+v"(cTagU), "+v"(cM3), "+v"(cM7), "+v"(cF0), "+v"(cF000));
+
+	const int orgA = imax(cA * CB, blA), orgB = imax(cB * CB, blB);
+	/* halves that start from a column checkpoint (the others start at their lane's first step, from the border) */
+	const uint32_t mck = (cA * CB > blA ? 0x0000ffffu : 0u) | (cB * CB > blB ? 0xffff0000u : 0u);
+	const int i0A = blA * K, i0B = blB * K;
+	/* row checkpoint entries of the row above my band: band 0 reads the border row (entry = column), the others the lane above
+	 * (entry e = state after step e - 1).  p = the entry of step org - 1 -- the cell diagonally above my first one */
+	const int sA = blA == 0 ? ES : 64 * ES, sB = blB == 0 ? ES : 64 * ES;
+	const int pA = blA == 0 ? a.off_brow + orgA * ES : a.off_rck + ((orgA - 1) * 64 + grp * G + blA - 1) * ES;
+	const int pB = blB == 0 ? a.off_brow + orgB * ES : a.off_rck + ((orgB - 1) * 64 + grp * G + blB - 1) * ES;
+	/* ---- the row above my two blocks, CB + 1 entries from step org - 1 on, staged in LDS as the lane below sees it: X' = max(L, M,
+	 *      U[, J]) with the winner's tag, and L of the row below = max(L + e, M + o).  All loads are issued before the state arrays
+	 *      exist (registers are free now) and cost one round trip; the step loop then reads two words per step from LDS. ---- */
+	const int stg = a.off_bound + lane * 2;
+	{
+		typedef typename std::conditional<ES == 4, uint4, ck_u3>::type ent_t;
+		ent_t ra[CB + 1], rb[CB + 1];
+#pragma unroll
+		for (int x = 0; x <= CB; ++x) { ra[x] = *(const ent_t *)(gs + pA + x * sA); rb[x] = *(const ent_t *)(gs + pB + x * sB); }
+#pragma unroll
+		for (int x = 0; x <= CB; ++x) {
+			const uint32_t eL = lohi(ra[x].x, rb[x].x), eM = lohi(ra[x].y, rb[x].y), eU = lohi(ra[x].z, rb[x].z);
+			uint32_t xx = pmax(pmax(eL | cTagL, eM | cTagM), eU | cTagU);
+			if constexpr (ES == 4) xx = pmax(xx, lohi(ra[x].w, rb[x].w));
+			mem.st2(stg + x * 128, xx, pmax(padd(eL | cTagL, e2), padd(eM | cTagM, o2)));
+		}
+	}
+
+	uint32_t Mo_l[K], U_l[K], Xl[2][K], J_l[HASJ ? K : 1], qsel[K], acc[K];
+	uint32_t jA[HASJ ? KG : 1], jB[HASJ ? KG : 1];
+	(void)jA; (void)jB; (void)J_l;
+	/* ---- the state at step org - 1 ---- */
+	uint32_t Ad, lraw0;
+	{
+		const uint2 e0 = mem.ld2(stg);
+		Ad = e0.x; lraw0 = e0.y;
+	}
+	{
+		/* the column checkpoint's values (M + o of my K rows, then U, then J: untagged) straight into the state arrays */
+		const int ckA = a.off_cck + (cA * NQ * 64 + grp * G + blA) * 4, ckB = a.off_cck + (cB * NQ * 64 + grp * G + blB) * 4;
+		auto put = [&](auto XC, uint32_t val) {
+			constexpr int x = decltype(XC)::value;
+			if constexpr (x < K) Mo_l[x] = val;
+			else if constexpr (x < 2 * K) U_l[x - K] = val;
+			else if constexpr (HASJ && x < 3 * K) J_l[x - 2 * K] = val;
+		};
+		uint4 cva[NQ], cvb[NQ];
+#pragma unroll
+		for (int q = 0; q < NQ; ++q) { cva[q] = *(const uint4 *)(gs + ckA + q * 256); cvb[q] = *(const uint4 *)(gs + ckB + q * 256); }
+		auto chunk = [&](auto QC) {
+			constexpr int q = decltype(QC)::value;
+			const uint4 va = cva[q], vb = cvb[q];
+			put(std::integral_constant<int, 4 * q>{}, lohi(va.x, vb.x)); put(std::integral_constant<int, 4 * q + 1>{}, lohi(va.y, vb.y));
+			put(std::integral_constant<int, 4 * q + 2>{}, lohi(va.z, vb.z)); put(std::integral_constant<int, 4 * q + 3>{}, lohi(va.w, vb.w));
+		};
+		static_for<NQ>(chunk);
+		uint32_t lraw = lraw0;                 /* L of my first row in the checkpoint's column */
+		/* the query words my bands' rows lie in (a band of K rows spans NWQ sequence words at most), fetched together */
+		constexpr int BPW = 32 / BITS, LBP = BITS == 2 ? 4 : 2, NWQ = (K + BPW - 2) / BPW + 1;
+		const int wqa = imin(i0A, l1A - 1) >> LBP, wqb = imin(i0B, l1B - 1) >> LBP;
+		const int lwa = (l1A - 1) >> LBP, lwb = (l1B - 1) >> LBP;
+		uint32_t qwa[NWQ], qwb[NWQ];
+#pragma unroll
+		for (int x = 0; x < NWQ; ++x) { qwa[x] = qA[imin(wqa + x, lwa)]; qwb[x] = qB[imin(wqb + x, lwb)]; }
+#pragma unroll
+		for (int r = 0; r < K; ++r) {
+			const uint32_t vMo = Mo_l[r], vU = U_l[r];
+			uint32_t vJ = neg2;
+			if constexpr (HASJ) vJ = J_l[r];
+			int La, Ma, Ua, Lb, Mb, Ub;
+			border16<MODE>(i0A + r + 1, 0, o16, e16, La, Ma, Ua);
+			border16<MODE>(i0B + r + 1, 0, o16, e16, Lb, Mb, Ub);
+			La = sat16(La); Lb = sat16(Lb);
+			const uint32_t bMo = pk2h(sat16((Ma | TGM) + o16), sat16((Mb | TGM) + o16));
+			const uint32_t bU = pk2h(Ua | TGU, Ub | TGU);
+			const uint32_t bX = pk2h(imax3(La | TGL, Ma | TGM, Ua | TGU), imax3(Lb | TGL, Mb | TGM, Ub | TGU));
+			/* from the checkpoint: M + o and U as stored (untagged), L by the chain down the column */
+			const uint32_t kMo = vMo | cTagM, kU = vU | cTagU;
+			const uint32_t Lc = lraw | cTagL, Mc = psub(vMo, o2) | cTagM;
+			uint32_t kX = pmax(pmax(Lc, Mc), kU);
+			if constexpr (HASJ) kX = pmax(kX, vJ);
+			lraw = pmax(padd(Lc, e2), kMo);
+			Mo_l[r] = vbfi(mck, kMo, bMo);
+			U_l[r] = vbfi(mck, kU, bU);
+			Xl[0][r] = vbfi(mck, kX, bX);
+			Xl[1][r] = Xl[0][r];
+			if constexpr (HASJ) J_l[r] = vbfi(mck, vJ, neg2);
+			/* my query bases, per half its own band's rows */
+			const int qi = imin(i0A + r, l1A - 1), qj = imin(i0B + r, l1B - 1);
+			const uint32_t wa = pick<NWQ>(qwa, (qi >> LBP) - wqa), wb = pick<NWQ>(qwb, (qj >> LBP) - wqb);
+			uint32_t ca, cb;
+			if constexpr (BITS == 2) { ca = (wa >> ((qi & 15) * 2)) & 3u; cb = (wb >> ((qj & 15) * 2)) & 3u; }
+			else { ca = (wa >> ((qi & 3) * 8)) & 0xffu; cb = (wb >> ((qj & 3) * 8)) & 0xffu; }
+			qsel[r] = (ca * 0x00000101u + cb * 0x01010000u) | (BITS == 2 ? 0x04000400u : 0u);
+			acc[r] = 0;
+		}
+	}
+	if constexpr (HASJ) {
+#pragma unroll
+		for (int g = 0; g < KG; ++g) { jA[g] = 0; jB[g] = 0; }
+	}
+	const int jA0 = orgA - blA, jB0 = orgB - blB;      /* column - 1 of step org */
+
+	for (int s4 = 0; s4 < CB / 4; ++s4) {
+		/* ---- s2 windows of the block's next 4 steps, per half from its own alignment's bytes ---- */
+		uint32_t wA, wB, smA = 0, smB = 0;
+		{
+			const int eA = jA0 + 4 * s4 + kPad, eB = jB0 + 4 * s4 + kPad;
+			const int xa = refoff + (eA >> 2), xb = refoff + a.off_refb + (eB >> 2);
+			const uint32_t a0 = mem.ld(xa), a1 = mem.ld(xa + 1), b0 = mem.ld(xb), b1 = mem.ld(xb + 1);
+			wA = __builtin_amdgcn_alignbit(a1, a0, (eA & 3) * 8);
+			wB = __builtin_amdgcn_alignbit(b1, b0, (eB & 3) * 8);
+		}
+		if constexpr (HASJ) {
+			const int eA = jA0 + 4 * s4 + 1 + 64, eB = jB0 + 4 * s4 + 1 + 64;
+			smA = __builtin_amdgcn_alignbit(mem.ld(a.off_sm + (eA >> 5) + 1), mem.ld(a.off_sm + (eA >> 5)), eA & 31);
+			smB = __builtin_amdgcn_alignbit(mem.ld(a.off_sm + (eB >> 5) + 1), mem.ld(a.off_sm + (eB >> 5)), eB & 31);
+		}
+		auto step = [&](auto KC) {
+			constexpr int k = decltype(KC)::value;
+			constexpr uint32_t SELK = (uint32_t)k * 0x00000101u + (uint32_t)(4 + k) * 0x01010000u;
+			const uint2 eup = mem.ld2(stg + (1 + 4 * s4 + k) * 128);   /* the row above in this step's column */
+			const uint32_t Aup = eup.x, Bup = eup.y;
+			uint32_t gopen = neg2;
+			if constexpr (HASJ) gopen = lohi(((smA >> k) & 1u) ? gmo2 : neg2, ((smB >> k) & 1u) ? gmo2 : neg2);
+			const uint32_t selw = __builtin_amdgcn_perm(wB, wA, SELK);
+			uint32_t diag = Ad, lraw = Bup, jn = 0;
+			(void)jn;
+#pragma unroll
+			for (int r = 0; r < K; ++r) {
+				/* (the row-step of the one-pass kernels with pointers, sweep16_items: same candidates, same tags, same cells) */
+				uint32_t S;
+				if constexpr (BITS == 2) S = __builtin_amdgcn_perm(lut_hi, lut_lo, selw ^ qsel[r]);
+				else S = pmad(pminu(selw ^ qsel[r], c1), umm2, m2);
+				uint32_t Mraw = padd(diag, S);
+				if constexpr (MODE == K_LOCAL) Mraw = pmax(Mraw, 0u);
+				const uint32_t Mc = vandor(Mraw, cClean, cTagM);
+				const uint32_t Lc = lraw | cTagL;
+				const uint32_t Uraw = pmax(Mo_l[r], padd(U_l[r], e2));
+				const uint32_t Uc = vandor(Uraw, cClean, cTagU);
+				const uint32_t Mo = padd(Mc, o2);
+				uint32_t Xo = pmax(pmax(Lc, Mc), Uc);
+				uint32_t Jraw = 0;
+				if constexpr (HASJ) {
+					Jraw = pmax(padd(Mo_l[r], gopen), J_l[r]);
+					const uint32_t Jc = Jraw & cClean;
+					Xo = pmax(Xo, Jc);
+					J_l[r] = Jc;
+				}
+				const uint32_t Ld = pmax(padd(Lc, e2), Mo);
+				uint32_t c;
+				if constexpr (TS == 4) c = vbfi(cM7, vbfi(cM3, Mraw, lraw), Uraw);
+				else c = vbfi(cM7, vbfi(cM3, Mraw, pshln<2>(lraw)), pshln<3>(Uraw));
+				if constexpr (HASJ) {
+					const int q = r & 3, gq = r >> 2;
+					if (q == 0) jn = Jraw;
+					else if (q == 1) jn = __builtin_amdgcn_perm(Jraw, jn, 0x06020400u);
+					else if (q == 2) jn = vbfi(cF0, pshln<4>(Jraw), jn);
+					else jn = vbfi(cF000, pshln<12>(Jraw), jn);
+					if (q == 3 || r == K - 1) {
+						if (q == 0) jn &= 0x000f000fu; else if (q == 1) jn &= 0x0f0f0f0fu; else if (q == 2) jn &= 0x0fff0fffu;
+						if constexpr (k == 0) jA[gq] = jn;
+						else if constexpr (k == 1) jA[gq] = vbfi(c8888, jn, jA[gq]);
+						else if constexpr (k == 2) jB[gq] = jn;
+						else jB[gq] = vbfi(c8888, jn, jB[gq]);
+					}
+				}
+				if constexpr (k == 0) acc[r] = c;
+				else if constexpr (k == 1) acc[r] = __builtin_amdgcn_perm(c, acc[r], 0x06020400u);
+				else if constexpr (k == 2) acc[r] = vbfi(cF0, pshln<4>(c), acc[r]);
+				else acc[r] = vbfi(cF000, pshln<12>(c), acc[r]);
+				diag = Xl[k & 1][r];
+				Xl[(k & 1) ^ 1][r] = Xo;
+				lraw = Ld;
+				Mo_l[r] = Mo; U_l[r] = Uc;
+			}
+			Ad = Aup;
+		};
+		step(std::integral_constant<int, 0>{}); step(std::integral_constant<int, 1>{});
+		step(std::integral_constant<int, 2>{}); step(std::integral_constant<int, 3>{});
+		/* ---- the pointer words of these 4 steps: [s4][row][lane], four rows of a lane adjacent (pidx) ---- */
+		{
+			constexpr int KQ = (K + 3) / 4;
+#pragma unroll
+			for (int r = 0; r < K; r += 4)
+				*(uint4 *)(gs + a.off_rptr + ridx<KQ>(s4, r, lane)) = make_uint4(acc[r], r + 1 < K ? acc[r + 1 < K ? r + 1 : 0] : 0u, r + 2 < K ? acc[r + 2 < K ? r + 2 : 0] : 0u, r + 3 < K ? acc[r + 3 < K ? r + 3 : 0] : 0u);
+		}
+		if constexpr (HASJ) {
+			constexpr int GQ = (KG + 3) / 4;
+			uint32_t jO[KG];
+#pragma unroll
+			for (int g = 0; g < KG; ++g) jO[g] = jA[g] | (jB[g] >> 1);
+#pragma unroll
+			for (int g = 0; g < KG; g += 4)
+				*(uint4 *)(gs + a.off_rjpl + ridx<GQ>(s4, g, lane)) = make_uint4(jO[g], g + 1 < KG ? jO[g + 1 < KG ? g + 1 : 0] : 0u, g + 2 < KG ? jO[g + 2 < KG ? g + 2 : 0] : 0u, g + 3 < KG ? jO[g + 3 < KG ? g + 3 : 0] : 0u);
+		}
+	}
+}
+
 /* The work items [wbase, wbase + items of `a`) of one launch, pulled from the launch's work counter: `wnext` is the item this wave
  * holds when it gets here (its block index, or what an earlier call left over); returns the first item beyond the range. */
-template <int MODE, int G, int K, int TS, bool SMALL, bool PTRLDS, bool TB, bool RAG = false, int BITS = 2>
+template <int MODE, int G, int K, int TS, bool SMALL, bool PTRLDS, bool TB, bool RAG = false, int BITS = 2, int CK = 0>
 AT_DEV long long sweep16_items(const Sweep16Args &a, long long wnext, const long long wbase)
 {
+	/* CK > 0: two-pass tracebacks -- the scores-only sweep leaves checkpoints every CK steps, the pointers are rebuilt block by block
+	 * where the walks need them (replay16_block above) */
+	constexpr bool TP = CK > 0;
+	static_assert(!TP || (!TB && !RAG && MODE != K_OVERLAP && !PTRLDS), "two-pass tracebacks: uniform batches of the affine modes, checkpoints in the global slot");
 	static_assert(BITS == 2 || BITS == 8, "sequence words: 16 two-bit codes or 4 bytes");
 	static_assert(!RAG || G <= 32 || MODE == K_OVERLAP, "ragged frames: one strip (the host sizes the frame for it)");
 	static_assert(MODE == K_GLOBAL || MODE == K_LOCAL || MODE == K_FIT || MODE == K_FITJ || MODE == K_OVERLAP, "packed path: the affine modes, overlap");
@@ -252,7 +624,9 @@ AT_DEV long long sweep16_items(const Sweep16Args &a, long long wnext, const long
 	 * unroll to ~6 KB of code and only one (masked) body is emitted: every launch starts with a cold instruction
 	 * cache, and at ~1 ms per launch the first pass through tens of KB of straight-line code is measurable. */
 	constexpr int BLK = G <= 16 ? 4 : 8;
-	constexpr bool ONEBODY = G <= 16;
+	/* (two-pass kernels carry the replay and the walks' code as well: one body keeps the whole kernel inside the instruction cache,
+	 * 64 KB for two CUs -- C3's forward sweep, replay and walks together are 58 KB with two bodies) */
+	constexpr bool ONEBODY = G <= 16 || (CK > 0 && AT_TP_ONEBODY);
 	constexpr int RPB = BLK / SPW;            /* pointer word rows per block */
 	constexpr int RS = G * K;                 /* rows per strip (G < 64: the only strip) */
 	constexpr int PADW = kPad / 4;            /* s2 bytes: 4 per word */
@@ -292,9 +666,26 @@ AT_DEV long long sweep16_items(const Sweep16Args &a, long long wnext, const long
 	const int jpl_base0 = a.off_ptr + __mul24(nstrips * wps, NL);
 	const long long nwork = (a.npairs + 2 * NG - 1) / (2 * NG);
 	const int refoff = grp * 2 * a.off_refb;  /* my group's two s2 byte arrays */
+	/* two-pass tracebacks: this wave's slot holds the checkpoints; row 0 of the matrix, the same for every alignment of the batch, is
+	 * written once as the row checkpoint of a lane above lane 0: entry j = (L, M, U[, J]) of cell (0, j) */
+	uint32_t *const gs = TP ? a.ws + (long long)blockIdx.x * a.ws_slot_words : nullptr;
+	constexpr int ES = ck_es<MODE>();
+	const int ck_T = tbk_frame * BLK;         /* steps of a sweep */
+	(void)gs; (void)ck_T;
+	if constexpr (TP) {
+		for (int j = lane; j <= l2; j += 64) {
+			int L, M, U;
+			border16<MODE>(0, j, o16, e16, L, M, U);
+			gs[a.off_brow + j * ES] = pk2(sat16(L)); gs[a.off_brow + j * ES + 1] = pk2(M); gs[a.off_brow + j * ES + 2] = pk2(U);
+			if constexpr (ES == 4) gs[a.off_brow + j * ES + 3] = 0x80008000u;
+		}
+	}
 
 	while (wnext - wbase < nwork) {
 		const long long wk = wnext - wbase;
+		long long st_item = 0;
+		(void)st_item;
+		if (TP && AT_TP_STATS) st_item = (long long)__builtin_amdgcn_s_memtime();
 		wnext = next_work(a.queue, lane);   /* consumed at the end of this work item: latency hidden */
 		const long long last = a.npairs - 1;
 		long long pA = (wk * NG + grp) * 2 < a.npairs ? (wk * NG + grp) * 2 : last;
@@ -436,6 +827,17 @@ AT_DEV long long sweep16_items(const Sweep16Args &a, long long wnext, const long
 				Xl[0][r] = pk2(imax3(L | TGL, M | TGM, U | TGU));
 				if constexpr (OVL) Xl[0][r] = 0;  /* M(i,0) = 0 */
 				Xl[1][r] = Xl[0][r];
+			}
+			/* two-pass: (L, M, U[, J]) of my last row as of my latest step -- the border's until my first one; entry 0 of my row checkpoints */
+			uint32_t ckL = 0, ckM = 0, ckU = 0, ckJ = neg2;
+			int ck_p = a.off_rck + lane * ES;      /* where the entry of the current step goes */
+			(void)ckL; (void)ckM; (void)ckU; (void)ckJ; (void)ck_p;
+			if constexpr (TP) {
+				int L, M, U;
+				border16<MODE>(i0 + K, 0, o16, e16, L, M, U);
+				ckL = pk2(sat16(L)); ckM = pk2(M); ckU = pk2(U);
+				gs[ck_p] = ckL; gs[ck_p + 1] = ckM; gs[ck_p + 2] = ckU;
+				if constexpr (ES == 4) gs[ck_p + 3] = ckJ;
 			}
 			uint32_t A_prev = Xl[0][K - 1], B_prev = 0, Ad;
 			{
@@ -607,6 +1009,10 @@ AT_DEV long long sweep16_items(const Sweep16Args &a, long long wnext, const long
 								J_l[r] = Jc;
 							}
 							const uint32_t Ld = pmax(padd(Lc, e2), Mo);
+							if (TP && r == K - 1) {                /* what the lane below needs of this row */
+								ckL = Lc; ckM = Mc; ckU = Uc;
+								if constexpr (HASJ) ckJ = J_l[r];
+							}
 							if constexpr (RAG && MODE == K_GLOBAL) {
 								if (r == rl) { capL = vbfi(capmask, Lc, capL); capM = vbfi(capmask, Mc, capM); capU = vbfi(capmask, Uc, capU); }
 							}
@@ -689,6 +1095,12 @@ AT_DEV long long sweep16_items(const Sweep16Args &a, long long wnext, const long
 						if (wb && lane == 63) mem.st2(a.off_bound + 2 * (jm1 + 1), up, lraw);
 					}
 					Ad = Aup;
+					if constexpr (TP) {
+						/* row checkpoint entry t + 1: my last row after this step (a step outside the matrix repeats the entry before) */
+						ck_p += 64 * ES;
+						if constexpr (ES == 4) *(uint4 *)(gs + ck_p) = make_uint4(ckL, ckM, ckU, ckJ);
+						else { gs[ck_p] = ckL; gs[ck_p + 1] = ckM; gs[ck_p + 2] = ckU; }
+					}
 					if constexpr (TB) {
 						if constexpr (OVL && PB == 2) {
 							if constexpr ((k + 1) % SPW == 0) {
@@ -759,6 +1171,26 @@ AT_DEV long long sweep16_items(const Sweep16Args &a, long long wnext, const long
 				else { AT_STEPS16(T) }
 #undef AT_STEPS16
 				bx = bxn; bl = bln;
+				if constexpr (TP) {
+					/* column checkpoint c: (M + o, U[, J]) of my K rows after step c * CK - 1, in 16-byte chunks [c][chunk][lane] */
+					if ((t0 + BLK) % CK == 0) {
+						constexpr int NV = HASJ ? 3 : 2, NQ = ck_nq<MODE, K>();
+						const int cb = a.off_cck + (((t0 + BLK) / CK) * NQ * 64 + lane) * 4;
+						auto val = [&](auto XC) -> uint32_t {
+							constexpr int x = decltype(XC)::value;
+							if constexpr (x < K) return Mo_l[x];
+							else if constexpr (x < 2 * K) return U_l[x - K];
+							else if constexpr (x < NV * K) return J_l[x - 2 * K];
+							else return 0u;
+						};
+						auto chunk = [&](auto QC) {
+							constexpr int q = decltype(QC)::value;
+							*(uint4 *)(gs + cb + q * 256) = make_uint4(val(std::integral_constant<int, 4 * q>{}), val(std::integral_constant<int, 4 * q + 1>{}),
+							                                          val(std::integral_constant<int, 4 * q + 2>{}), val(std::integral_constant<int, 4 * q + 3>{}));
+						};
+						static_for<NQ>(chunk);
+					}
+				}
 			}
 			if constexpr (MODE == K_LOCAL) {
 				/* fold this strip's per-lane winner into the running one (earlier strips = smaller i win ties) */
@@ -847,6 +1279,238 @@ AT_DEV long long sweep16_items(const Sweep16Args &a, long long wnext, const long
 			}
 			my_sc = sc16; my_ci = ci; my_cj = cj; my_st = st; my_ok = ok;
 		}
+		if constexpr (TP) {
+			/* ================= two-pass tracebacks: rounds of { replay the blocks the walks are heading for; walk } ================= */
+			constexpr int LCB = ck_log2(CK);
+			constexpr int KG2 = (K + 3) / 4;
+			const int g2 = lane >> 1, h = lane & 1;
+			const long long pin = wk * 2 * NG + lane;
+			const bool mine = lane < 2 * NG && pin < a.npairs;
+			int ci = my_ci, cj = my_cj, st = my_st, cnt = 0;
+			bool ok = my_ok;
+			const bool walks = mine && a.nops != nullptr;
+			uint8_t *ops = walks ? a.ops + a.ops_off[pin] : nullptr;
+			/* the checkpoints of this item have been written by other lanes of this wave: stores done, stale L1 lines dropped */
+			asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+			__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+			if (AT_WALK_PRIO) __builtin_amdgcn_s_setprio(AT_WALK_PRIO);
+			CkPattern<G, K, CK> pat;
+			(void)KG2;
+			long long st_t0 = 0, st_rep = 0, st_walk = 0;
+			int st_rounds = 0, st_fetch = 0;
+			(void)st_t0; (void)st_rep; (void)st_walk; (void)st_rounds; (void)st_fetch;
+			if (AT_TP_STATS) st_t0 = (long long)__builtin_amdgcn_s_memtime();
+			for (int rounds = 0;; ++rounds) {
+				/* has my walk arrived?  local: HOME (:788-791) or a border; global: a border (then the padding loops); fit: row 0 */
+				const bool fin = !walks || !ok || ci <= 0 || (!ISFIT && cj <= 0) || (MODE == K_LOCAL && st == 0) || AT_DIAG_NO_WALK;
+				if (!fin && (cj <= 0 || cnt >= own_len)) ok = false;         /* (fit: the walk left the matrix; or more ops than the slot holds) */
+				bool go = !fin && ok;
+				if (rounds > own_len + 8) { if (go) ok = false; go = false; }   /* (every round moves every walk: cannot happen) */
+				if (!__any(go)) break;
+				/* a walk in U (1) or the jump state (0, fit -s only) runs left along its row; in M or L it climbs */
+				pat.set(go ? ci : 1, go ? cj : 1, st == 1 || (HASJ && st == 0));
+				/* the anchors of my group's two alignments (their walkers are lanes 2 * grp and 2 * grp + 1) -> my two blocks */
+				int blk_bl[2], blk_c[2];
+#pragma unroll
+				for (int hh = 0; hh < 2; ++hh) {
+					CkPattern<G, K, CK> q;
+					q.b = __shfl(pat.b, 2 * grp + hh); q.c0 = __shfl(pat.c0, 2 * grp + hh);
+					q.thi1 = __shfl(pat.thi1, 2 * grp + hh); q.horiz = __shfl(pat.horiz, 2 * grp + hh);
+					const int alive = __shfl(go ? 1 : 0, 2 * grp + hh);
+					bool v;
+					q.block(lg, ck_T, blk_bl[hh], blk_c[hh], v);
+					if (!v || !alive) { blk_bl[hh] = 0; blk_c[hh] = 0; }   /* (a slot nobody reads: the first block of band 0) */
+				}
+				long long st_a = 0;
+				if (AT_TP_STATS) { st_a = (long long)__builtin_amdgcn_s_memtime(); ++st_rounds; }
+				replay16_block<MODE, G, K, TS, SMALL, BITS, CK>(a, mem, gs, refoff, qA, qB, l1A, l1B, blk_bl[0], blk_c[0], blk_bl[1], blk_c[1]);
+				asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        /* the blocks' pointer words are in the L2 */
+				if (AT_TP_STATS) st_rep += (long long)__builtin_amdgcn_s_memtime() - st_a;
+				/* (the replay's staging area in LDS is free again: every walker copies the block it is in -- K x CK cells, KQ * CK words [+ the
+				 * jump plane's] -- from the slot into its own piece of it with one round trip, and walks it from there) */
+				__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");      /* drop this CU's L1 lines of the replay region: last round's words */
+				if (AT_TP_STATS) st_a = (long long)__builtin_amdgcn_s_memtime();
+				{
+					constexpr int KQ = (K + 3) / 4, GQ = (KG2 + 3) / 4, S4N = CK / 4;
+					constexpr int WSCR = ck_walk_words<MODE, K, CK>();
+					constexpr int NBLK = ck_walk_blocks<G>();                             /* blocks a walker holds in LDS at a time */
+					constexpr int NCHP = S4N * KQ, NCH = NCHP + (HASJ ? S4N * GQ : 0);   /* 16-byte chunks of a block: pointer words, then the plane's */
+					constexpr int LPW = 64 / (2 * NG), CPL = (NBLK * NCH + LPW - 1) / LPW;   /* lanes that copy for one walker, chunks per lane */
+					const int sl0 = g2 * G;                               /* lane 0 of my alignment's group: slot q = lane sl0 + q */
+					const int scr0 = a.off_bound + lane * (NBLK * WSCR);
+					bool wgo = go;
+					(void)GQ;
+					/* phases: every walker names the block it is in (and, where LDS has room, the blocks up and left of it); the wave copies
+					 * them from the slot into LDS together (LPW lanes per walker, one round trip for all of them); every walker walks until
+					 * it leaves what it holds.  A walker leaves the phases when it has arrived or stands in a block this round has not
+					 * replayed */
+					for (;;) {
+						int need[NBLK], tbl[NBLK], tc[NBLK];
+#pragma unroll
+						for (int k = 0; k < NBLK; ++k) { need[k] = -1; tbl[k] = -1; tc[k] = -1; }
+						if (wgo) {
+							if (ci <= 0 || (!ISFIT && cj <= 0) || (MODE == K_LOCAL && st == 0)) wgo = false;
+							else if (cj <= 0 || cnt >= own_len || (st == 0 && !HASJ)) { ok = false; wgo = false; }   /* (st = 0 without a jump state: a corrupt pointer) */
+							else {
+								const int bl = (ci - 1) / K, rr = (ci - 1) - bl * K;
+								const int c = ((cj - 1) + bl) >> LCB;
+								const int q = pat.slot(bl, c);
+								if (q < 0) wgo = false;                       /* (outside this round's blocks: the next round starts here) */
+								else {
+									need[0] = sl0 + q; tbl[0] = bl; tc[0] = c;
+									if constexpr (NBLK == 4) {
+										/* the block left of mine, and the two the diagonal through my cell meets in the band above */
+										const int c2 = ((cj - 1) - (rr + 1) + (bl - 1)) >> LCB;
+										const int q1 = pat.slot(bl, c - 1), q2 = bl > 0 ? pat.slot(bl - 1, c2) : -1, q3 = bl > 0 ? pat.slot(bl - 1, c2 - 1) : -1;
+										if (q1 >= 0) { need[1] = sl0 + q1; tbl[1] = bl; tc[1] = c - 1; }
+										if (q2 >= 0) { need[2] = sl0 + q2; tbl[2] = bl - 1; tc[2] = c2; }
+										if (q3 >= 0) { need[3] = sl0 + q3; tbl[3] = bl - 1; tc[3] = c2 - 1; }
+									}
+								}
+							}
+						}
+						if (!__any(need[0] >= 0)) break;
+						long long st_f0 = 0;
+						if (AT_TP_STATS) st_f0 = (long long)__builtin_amdgcn_s_memtime();
+						{
+							const int w = lane / LPW, part = lane % LPW;
+							const int dst = a.off_bound + w * (NBLK * WSCR);
+							int src[NBLK];
+#pragma unroll
+							for (int k = 0; k < NBLK; ++k) src[k] = __shfl(need[k], w);
+							uint4 tw[CPL];
+#pragma unroll
+							for (int x = 0; x < CPL; ++x) {
+								const int id = part + x * LPW, k = id / NCH, ch = id - k * NCH;   /* chunk ch of block k: words [ch][slot lane][4] of its region */
+								const int sl = imax(NBLK == 1 ? src[0] : pick<NBLK>(src, imin(k, NBLK - 1)), 0);
+								const uint32_t *from = gs + (ch < NCHP ? a.off_rptr + (ch * 64 + sl) * 4 : a.off_rjpl + ((ch - NCHP) * 64 + sl) * 4);
+								asm volatile("global_load_dwordx4 %0, %1, off" : "=&v"(tw[x]) : "v"(from) : "memory");
+							}
+							asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+							for (int x = 0; x < CPL; ++x) {
+								const int id = part + x * LPW, k = id / NCH, ch = id - k * NCH;
+								const int sl = NBLK == 1 ? src[0] : pick<NBLK>(src, imin(k, NBLK - 1));
+								if (sl >= 0 && k < NBLK) *(uint4 *)(&at_lds[dst + k * WSCR + 4 * ch]) = tw[x];
+							}
+							__builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+						}
+						if (AT_TP_STATS) st_fetch += (int)((long long)__builtin_amdgcn_s_memtime() - st_f0);
+						if (need[0] >= 0) {
+							int kb = 0;                                       /* the block of mine I am in */
+							for (;;) {
+								const int bl = NBLK == 1 ? tbl[0] : pick<NBLK>(tbl, kb), c = NBLK == 1 ? tc[0] : pick<NBLK>(tc, kb);
+								const int scr = scr0 + kb * WSCR, scj = scr + KQ * CK;
+								(void)scj;
+								const int i_lo = bl * K, t_lo = imax(c << LCB, bl) - bl;   /* row (0-based) and column - 1 of the block's first cell */
+								for (;;) {
+									/* inside the block both offsets are >= 0.  st = 0: HOME, or nothing at all (the phase loop sorts it out), or the jump state */
+									const int rr = ci - 1 - i_lo, ss = cj - 1 - t_lo;
+									if ((rr | ss) < 0 || cnt >= own_len || (st == 0 && !HASJ)) break;
+									if constexpr (HASJ) {
+										if (st == 0) {
+											/* jump state (:579-583): left along the row until the column where J opened from M.  A plane word holds my row's
+											 * bits of 4 steps, {step 1, step 3, step 0, step 2}; up to 4 words -- 16 columns -- put in column order, the steps
+											 * behind mine shifted out: the first set bit is where J opened */
+											constexpr unsigned long long ORD = 0xfbea7362d9c85140ull;
+											const int s4 = ss >> 2, tk = ss & 3;
+											uint32_t cols = 0;
+#pragma unroll
+											for (int x = 0; x < 4; ++x) {
+												const uint32_t w = at_lds[scj + imax(s4 - x, 0) * (GQ * 4) + (rr >> 2)];
+												const uint32_t nib = (w >> (16 * h + cell_shift<4>(rr & 3))) & 15u;
+												cols = (cols << 4) | ((uint32_t)(ORD >> (4 * nib)) & 15u);
+											}
+											cols = (cols << (3 - tk)) & 0xffffu;                         /* bit 15 = column cj */
+											const int avail = 4 * imin(4, s4 + 1) - (3 - tk);          /* columns of this block from mine leftwards */
+											const int lim = imin(imin(avail, cj), own_len - cnt);
+											const int n = __clz((int)((cols << 16) | 0x8000u));
+											const int steps = n < lim ? n + 1 : lim;
+											if (n < lim) st = 2;
+											for (int x = 0; x < steps; ++x) ops[cnt + x] = 3;
+											cnt += steps; cj -= steps;
+											continue;
+										}
+									}
+									/* while its state does not change a walk keeps its direction (LOW up, MID diagonal, UPP left) and its op: the cells of
+									 * the next four ops along it are read together; n of them are consumed -- up to the first one that changes the state,
+									 * the block's edge, the end of the ops slot */
+									const int inL = st == 3, inM = st == 2;
+									const int di = inL | inM, dj = inL ^ 1;
+									/* (the state machine in bit arithmetic: written with selects hipcc makes branches of it, and a wait between the reads) */
+									const uint32_t mL = 0u - (uint32_t)inL, mM = 0u - (uint32_t)inM, mU = ~(mL | mM);
+									uint32_t nbv[4], nst[4];
+									int shv[4];
+#pragma unroll
+									for (int x = 0; x < 4; ++x) {
+										const int rx = imax(rr - x * di, 0), sx = imax(ss - x * dj, 0);
+										nbv[x] = at_lds[scr + (sx >> 2) * (KQ * 4) + rx];
+										shv[x] = 16 * h + ((sx & 1) << 3) + ((sx & 2) << 1);
+									}
+#pragma unroll
+									for (int x = 0; x < 4; ++x) {
+										/* {bit 3: U winner, bit 2: L extended, pM[1:0]} -- the cells of the one-pass kernels.  In L: LOW 3 if it extended, else
+										 * MID 2; in M: pM; in U: MID 2 if it opened (bit 3 with scores x16, its complement with x4), else UPP 1 */
+										const uint32_t nb = nbv[x] >> shv[x];
+										const uint32_t lres = 2u + ((nb >> 2) & 1u), mres = nb & 3u, ures = TS == 4 ? 1u + ((nb >> 3) & 1u) : 2u - ((nb >> 3) & 1u);
+										nst[x] = (lres & mL) | (mres & mM) | (ures & mU);
+									}
+									const uint32_t ust = (uint32_t)st;
+									const int e0 = nst[0] == ust, e1 = e0 & (nst[1] == ust), e2 = e1 & (nst[2] == ust);
+									const int lim = imin(imin(di ? rr : 3, dj ? ss : 3), own_len - cnt - 1);       /* ops beyond the first that stay inside */
+									const int n = imin(1 + e0 + e1 + e2, lim + 1);
+									const uint32_t op4 = ((uint32_t)inL | (2u & mU)) * 0x01010101u;      /* LOW 1, MID 0, UPP 2 */
+									if (__builtin_expect(cnt + 4 <= own_len, 1)) __builtin_memcpy(ops + cnt, &op4, 4);   /* (bytes behind the walk's end are rewritten or never read) */
+									else {
+#pragma nounroll
+										for (int x = 0; x < n; ++x) ops[cnt + x] = (uint8_t)op4;
+									}
+									st = (int)(n == 1 ? nst[0] : n == 2 ? nst[1] : n == 3 ? nst[2] : nst[3]);
+									ci -= n * di; cj -= n * dj; cnt += n;
+								}
+								if constexpr (NBLK == 1) break;
+								else {
+									/* off this block: into another one I hold? */
+									if (ci <= 0 || cj <= 0 || cnt >= own_len || st == 0) break;
+									const int nbl = (ci - 1) / K, nc = ((cj - 1) + nbl) >> LCB;
+									int kn = -1;
+#pragma unroll
+									for (int k = 0; k < NBLK; ++k) kn = (tbl[k] == nbl && tc[k] == nc) ? k : kn;
+									if (kn < 0 || kn == kb) break;
+									kb = kn;
+								}
+							}
+						}
+					}
+				}
+				if (AT_TP_STATS) st_walk += (long long)__builtin_amdgcn_s_memtime() - st_a;
+			}
+			if (AT_WALK_PRIO) __builtin_amdgcn_s_setprio(0);
+			if (AT_TP_STATS) {
+				const long long now = (long long)__builtin_amdgcn_s_memtime();
+				int mxf = st_fetch;
+				if (lane == 0) {
+					atomicAdd(a.queue + 1, 1ull); atomicAdd(a.queue + 2, (unsigned long long)st_rounds);
+					atomicAdd(a.queue + 3, (unsigned long long)st_walk); atomicAdd(a.queue + 4, (unsigned long long)mxf);
+					atomicAdd(a.queue + 5, (unsigned long long)(now - st_t0)); atomicAdd(a.queue + 6, (unsigned long long)st_rep);
+					atomicAdd(a.queue + 7, (unsigned long long)(st_t0 - st_item));
+				}
+			}
+			if (mine) {
+				if constexpr (MODE == K_GLOBAL) {                         /* padding loops :398-407 */
+					if (walks && ok && !AT_DIAG_NO_WALK) {
+						while (cj > 0 && cnt < own_len) { ops[cnt++] = 2; --cj; }
+						while (ci > 0 && cnt < own_len) { ops[cnt++] = 1; --ci; }
+						if (ci > 0 || cj > 0) ok = false;
+					}
+				}
+				a.score[pin] = ok ? (my_sc >> TS) : INT32_MIN;
+				if (a.end_i) a.end_i[pin] = my_ci;
+				if (a.end_j) a.end_j[pin] = my_cj;
+				if (a.state) a.state[pin] = my_st == 3 ? 1 : my_st == 2 ? 2 : 3;
+				if (a.nops) a.nops[pin] = ok ? cnt : -1;
+			}
+		} else
 		/* ================= results; tracebacks: the 2*NG pointer walks run side by side, one per lane, so their
 		 *                   dependent pointer loads overlap instead of queueing behind each other ================= */
 		{
@@ -1029,16 +1693,16 @@ constexpr int at_tail_k(int g, int k)
  * long) that follow the main items in the same work queue -- a launch that has the chip to itself then ends with a fifth of the
  * SIMDs busy for a short item instead of a tenth of them working through one long item more (C2: 6 250 items of 16 pairs on 2 048
  * resident waves = 3.05 rounds).  t.npairs = 0: no sliver.  Other kernels ignore `t`. */
-template <int MODE, int G, int K, int TS, bool SMALL, bool PTRLDS, bool TB, bool RAG = false, int BITS = 2>
-__global__ __launch_bounds__(64, AT_WAVES16(G, K)) void at_sweep16(const Sweep16Args a, const Sweep16Args t)
+template <int MODE, int G, int K, int TS, bool SMALL, bool PTRLDS, bool TB, bool RAG = false, int BITS = 2, int CK = 0>
+__global__ __launch_bounds__(64, (CK > 0 && G == 64 ? 2 : AT_WAVES16(G, K))) void at_sweep16(const Sweep16Args a, const Sweep16Args t)
 {
 	if (a.only_if && __builtin_amdgcn_readfirstlane(*a.only_if) != a.only_val) return;
-	long long w = sweep16_items<MODE, G, K, TS, SMALL, PTRLDS, TB, RAG, BITS>(a, (long long)blockIdx.x, 0);
+	long long w = sweep16_items<MODE, G, K, TS, SMALL, PTRLDS, TB, RAG, BITS, CK>(a, (long long)blockIdx.x, 0);
 	if constexpr (G <= 16 && !RAG && MODE != K_OVERLAP) {
 		if (t.npairs > 0) {
 			constexpr int NGm = 64 / G;
 			const long long nmain = (a.npairs + 2 * NGm - 1) / (2 * NGm);
-			sweep16_items<MODE, AT_TAIL_G, at_tail_k(G, K), TS, SMALL, PTRLDS, TB, false, BITS>(t, w, nmain);
+			sweep16_items<MODE, AT_TAIL_G, at_tail_k(G, K), TS, SMALL, PTRLDS, TB, false, BITS, CK>(t, w, nmain);
 		}
 	}
 }

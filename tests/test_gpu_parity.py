@@ -1489,3 +1489,73 @@ def test_host_entry_writes_only_its_slots(al):
         assert (b1[~written] == 0xEE).all(), "bytes outside the slots were written"
         if strings:
             assert (b2[~written] == 0xEE).all()
+
+
+@pytest.mark.parametrize("case", [
+    # mode, jump state, l1, l2, pairs, scoring, sites: what it reaches
+    ("global", False, 1024, 1024, 300, (1, -1, -4, -1, -10), []),             # 64 lanes x 16 rows, scores x4 (C3's shape)
+    ("local", False, 1000, 1024, 300, (2, -2, -5, -2, -10), []),              # scores x4, HOME inside a block
+    ("local", False, 700, 640, 400, (1, -1, -1, -1, -10), []),                # scores x16, tie-heavy, l2 < l1
+    ("fit", False, 700, 1024, 300, (1, -1, -4, -1, -10), []),
+    ("fit", True, 620, 660, 300, (1, -1, -4, -1, -6), [100, 450, 451, 600]),  # scores x16 with the jump plane on the 64-lane group
+    ("global", False, 620, 3000, 120, (1, -1, -1, -1, -10), []),              # 190 column blocks per lane
+    ("local", False, 150, 150, 700, (2, -2, -5, -2, -10), []),                # AT_TWO_PASS=2 only: 8 lanes x 19 rows (C2's shape)
+    ("fit", True, 150, 500, 500, (2, -2, -5, -1, -10), [100, 200, 300, 400]), # ... C4's shape
+    ("global", False, 129, 140, 500, (1, -1, -1, -1, -10), []),
+    ("fit", True, 140, 300, 500, (1, -1, -1, -1, -2), [7, 50, 51, 120]),
+])
+def test_two_pass_tracebacks(al, case, monkeypatch):
+    """Two-pass tracebacks (at_sweep16.hip.h, CK kernels: the scores-only sweep leaves checkpoints, the pointers are rebuilt block by
+    block where the walks go) against the one-pass kernels on the whole batch -- score, end cell, start state, ops -- and against the
+    oracle on a sample; related and unrelated pairs, batches that leave the last work item partly empty."""
+    mode, uj, l1, l2, n, sc, sites = case
+    rng = random.Random(l1 * 7919 + l2)
+
+    def mk(related):
+        a = "".join(rng.choice("ACGT") for _ in range(l1))
+        if not related:
+            return a, "".join(rng.choice("ACGT") for _ in range(l2))
+        t = list(a)
+        for _ in range(1 + l1 // 15):
+            q = rng.randrange(len(t))
+            r = rng.random()
+            if r < 0.5:
+                t[q] = rng.choice("ACGT")
+            elif r < 0.75 and len(t) > 1:
+                del t[q]
+            else:
+                t.insert(q, rng.choice("ACGT"))
+        return a, ("".join(rng.choice("ACGT") for _ in range(rng.randint(0, max(0, l2 - l1)))) + "".join(t) + "".join(rng.choice("ACGT") for _ in range(l2)))[:l2]
+
+    pairs = [mk(k % 2 == 1) for k in range(n - 3)]
+    al.set_scoring(*sc, uj, sites)
+    monkeypatch.setenv("AT_HOST_CHUNKS", "1")
+    monkeypatch.setenv("AT_TWO_PASS", "2")
+    two = al.align_batch(mode, pairs, traceback=True, render=False)
+    assert "two-pass" in al.last_config, al.last_config
+    monkeypatch.setenv("AT_TWO_PASS", "0")
+    one = al.align_batch(mode, pairs, traceback=True, render=False)
+    assert "two-pass" not in al.last_config, al.last_config
+    for key in ("score", "end_i", "end_j", "state", "nops"):
+        assert (np.asarray(two[key]) == np.asarray(one[key])).all(), (case, key)
+    assert two["ops"] == one["ops"], case
+    for k in range(0, len(pairs), max(1, len(pairs) // (12 if l1 > 300 else 60))):
+        r = O.align(O.MODE_NAMES[mode], pairs[k][0], pairs[k][1], *sc, uj, sites)
+        assert (int(two["score"][k]), int(two["end_i"][k]), int(two["end_j"][k]), int(two["state"][k])) == \
+               (r["score"], r["end_i"], r["end_j"], r["state"]), (case, k)
+        assert two["ops"][k] == r["ops"], (case, k)
+
+
+def test_two_pass_default_routing(al, monkeypatch):
+    """By default the two-pass kernels take the shapes on which they win (one strip of 64 lanes x 16 rows: reads of 609 .. 1 024
+    bases) and leave the others to the one-pass kernels."""
+    rng = random.Random(5)
+    monkeypatch.delenv("AT_TWO_PASS", raising=False)
+    monkeypatch.setenv("AT_HOST_CHUNKS", "1")
+    al.set_scoring(1, -1, -4, -1, -10, False, [])
+    for l1, want in ((1024, True), (609, True), (150, False), (1025, False)):
+        pairs = [("".join(rng.choice("ACGT") for _ in range(l1)), "".join(rng.choice("ACGT") for _ in range(l1 + 20))) for _ in range(40)]
+        al.align_batch("global", pairs, traceback=True, render=False)
+        assert ("two-pass" in al.last_config) == want, (l1, al.last_config)
+        al.align_batch("global", pairs, traceback=False, render=False)
+        assert "two-pass" not in al.last_config

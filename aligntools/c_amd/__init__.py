@@ -23,7 +23,7 @@ OP_MID, OP_LOW, OP_UPP, OP_JUMP = 0, 1, 2, 3
 ST_LOW, ST_MID, ST_UPP = 1, 2, 3
 
 # every symbol include/aligntools_hip.h declares
-ABI_SYMBOLS = ["at_init", "at_destroy", "at_last_error", "at_set_scoring", "at_align_batch",
+ABI_SYMBOLS = ["at_init", "at_destroy", "at_last_error", "at_set_scoring", "at_set_min_score", "at_align_batch",
                "at_align_batch_device", "at_align_allpairs_device", "at_render_batch_device", "at_compact_ops_device",
                "at_align_batch_strings", "at_align_allpairs", "at_align_allpairs_stream",
                "at_comm_init", "at_comm_broadcast_scoring", "at_comm_allgather", "at_comm_destroy", "at_comm_abi_checked",
@@ -87,6 +87,8 @@ def load_library():
     lib.at_last_config.argtypes = [C.c_void_p]
     lib.at_set_scoring.restype = C.c_int
     lib.at_set_scoring.argtypes = [C.c_void_p] + [C.c_int] * 6 + [C.POINTER(C.c_int), C.c_int]
+    lib.at_set_min_score.restype = C.c_int
+    lib.at_set_min_score.argtypes = [C.c_void_p, C.c_int, C.c_int32]
     lib.at_align_batch.restype = C.c_int
     lib.at_align_batch.argtypes = [C.c_void_p, C.c_int, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                    C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
@@ -233,6 +235,11 @@ class Aligner:
 
     def set_opt(self, opt):
         self.set_scoring(opt.m, opt.u, opt.o, opt.e, opt.j, opt.s, opt.sites)
+
+    def set_min_score(self, min_score=None):
+        """All-vs-all overlap scores: pairs proven to score below `min_score` are not swept (state 0, score = an upper bound);
+        None switches the threshold off (at_set_min_score)."""
+        self._check(self._lib.at_set_min_score(self._h, 0 if min_score is None else 1, 0 if min_score is None else int(min_score)))
 
     def align_batch_strings(self, mode, pairs):
         """pairs: list of (s1, s2) bytes/str.  The two gapped strings of every pair, rendered on the GPU

@@ -85,6 +85,7 @@ struct at_handle {
 	/* scoring */
 	int m = 1, u = -2, o = -5, e = -1, j = -10, use_jump = 0;
 	std::vector<int> sites;
+	int min_on = 0, min_score = 0;  /* at_set_min_score: all-vs-all overlap scores skip pairs proven below it */
 	/* device scratch (grow-only) */
 	uint32_t *d_sitemask = nullptr; size_t sitemask_words = 0; int sitemask_for_l2 = -1; bool sitemask_dirty = true;
 	uint32_t *d_ws = nullptr; size_t ws_bytes = 0;
@@ -127,6 +128,16 @@ static int fail(at_handle *h, int code, const char *fmt, ...)
 	snprintf(g_err, sizeof g_err, "%s", buf);
 	if (h) snprintf(h->err, sizeof h->err, "%s", buf);
 	return code;
+}
+
+/* no C++ exception crosses the C ABI (std::bad_alloc from a vector or a string on the host side): it becomes an error code */
+template <typename F>
+static int guarded(at_handle *h, const char *who, F &&body)
+{
+	try { return body(); }
+	catch (const std::bad_alloc &) { return fail(h, AT_ERR_NOMEM, "%s: out of host memory", who); }
+	catch (const std::exception &ex) { return fail(h, AT_ERR_NOMEM, "%s: %s", who, ex.what()); }
+	catch (...) { return fail(h, AT_ERR_NOMEM, "%s: unknown C++ exception", who); }
 }
 
 #define HIP_TRY(h, call)                                                                      \
@@ -225,6 +236,14 @@ extern "C" void at_destroy(at_handle *h)
 	if (h->copy_stream) (void)hipStreamDestroy(h->copy_stream);
 	if (h->stream) (void)hipStreamDestroy(h->stream);
 	delete h;
+}
+
+extern "C" int at_set_min_score(at_handle *h, int enabled, int32_t min_score)
+{
+	if (!h) return fail(nullptr, AT_ERR_ARG, "at_set_min_score: NULL handle");
+	h->min_on = enabled ? 1 : 0;
+	h->min_score = min_score;
+	return AT_OK;
 }
 
 extern "C" int at_set_scoring(at_handle *h, int m, int u, int o, int e, int j, int use_jump, const int *sites, int nsites)
@@ -537,9 +556,12 @@ static TpLayout tp_layout(const Layout16 &L, int kmode, int l2)
 
 static int choose_store(long long words_fixed, long long words_ptr, bool prefer_hbm_pointers);
 /* is there a packed instantiation for the storage class plan_launch will choose for this layout? */
-static bool packed16_kernel_exists(int kmode, const Layout16 &P, bool tb, int ts, int bits, int rag)
+static bool packed16_kernel_exists(int kmode, const Layout16 &P, bool tb, int ts, int bits, int rag, const Layout16 *PT = nullptr)
 {
-	const int st = choose_store(P.off_ptr, P.words - P.off_ptr, P.g < 64 || rag);   /* (ragged frames exist with the pointers in the global slots only) */
+	/* (the launch plans with the larger of the main items' layout and the sliver items': the same maximum here) */
+	const long long fixed = PT ? std::max(P.off_ptr, PT->off_ptr) : P.off_ptr;
+	const long long ptrw = PT ? std::max(P.words - P.off_ptr, PT->words - PT->off_ptr) : P.words - P.off_ptr;
+	const int st = choose_store(fixed, ptrw, P.g < 64 || rag);   /* (ragged frames exist with the pointers in the global slots only) */
 	if (P.g != 64 && st == 2) return false;
 	return (rag ? at_pick16_rag(kmode, P.g, P.k, st, tb, bits) : at_pick16(kmode, P.g, P.k, ts, st, tb, bits)) != nullptr;
 }
@@ -859,7 +881,10 @@ static int align_device(at_handle *h, int mode, int64_t npairs,
 		if (P.words >= (1LL << 24)) { if (rag) return fail(h, AT_ERR_ARG, "ragged packed launch outside its domain (slot too large)"); ts = 0; }
 		/* no packed kernel for the storage class this shape needs (the 16- and 32-lane groups have no all-HBM variant:
 		 * a 150-base read against a second sequence of more than ~4 000 bases): the int32 kernel takes any length */
-		if (ts && !packed16_kernel_exists(kmode, P, tb, ts, bits, rag)) {
+		Layout16 PTq = P;
+		const bool tailq = !rag && !only_if && P.g <= 16 && kmode != at::K_OVERLAP && env_ll("AT_TAIL_SPLIT", 1);
+		if (tailq) PTq = layout16_for(tb, kmode == at::K_FITJ, max_len1, max_len2, ts, at::AT_TAIL_G, false, kmode, at::at_tail_k(P.g, P.k));
+		if (ts && !packed16_kernel_exists(kmode, P, tb, ts, bits, rag, tailq ? &PTq : nullptr)) {
 			if (rag) return fail(h, AT_ERR_ARG, "ragged packed launch outside its domain (frame too long for LDS)");
 			ts = 0;
 		}
@@ -1004,6 +1029,47 @@ static int align_device(at_handle *h, int mode, int64_t npairs,
 		return AT_OK;
 	}
 
+	/* ---- all-vs-all overlap scores with a threshold (at_set_min_score): the bit-parallel filter (at_myers.hip.h, SEMI) bounds every
+	 * pair's score from above at a seventh of the sweep's cost; only pairs whose bound reaches the threshold are swept.  The filter
+	 * leaves (upper bound, state 0) in every pair's result slot and the candidates' indices in a list; the sweep below takes the
+	 * list and its length from the device and overwrites the candidates' slots with exact results.  No host round trip. ---- */
+	const int *npairs_dev = nullptr;
+	char filter_note[96] = "";
+	if (kmode == at::K_OVERLAP && !tb && ap_n > 0 && h->min_on && !d_order && !only_if && bits == 2 && max_len1 >= 1 && max_len1 <= 1024 &&
+	    npairs < (1LL << 31) - 64 && env_ll("AT_OVERLAP_FILTER", 1)) {
+		/* 2 score <= 2 m b - (2 c - m) D', c = min(m - u, m / 2 - o): needs m >= 0 and 2 c > m */
+		const long long k2 = std::min<long long>(2LL * (h->m - h->u), (long long)h->m - 2LL * h->o) - h->m;
+		auto windows = [&](int n) { return (size_t)n * ((((size_t)max_len2 + 15) / 16 + 2) | 1) * 4; };
+		const int w = max_len1 <= 64 ? 2 : max_len1 <= 96 ? 3 : max_len1 <= 128 ? 4 : max_len1 <= 160 ? 5 : max_len1 <= 256 ? 8 : max_len1 <= 512 ? 16 : 32;
+		at_myers_fn ffn = at_pick_myers_semi(w);
+		if (h->m >= 0 && k2 > 0 && k2 < 4096 && h->m < 4096 && windows(64) <= 60 * 1024 && ffn) {
+			int rc = grow(h, &h->d_order, &h->order_bytes, ((size_t)npairs + 64) * 4);
+			if (rc) return rc;
+			int *cand = (int *)h->d_order, *count = cand + ((npairs + 15) & ~15LL);
+			HIP_TRY(h, hipMemsetAsync(count, 0, 4, stream));
+			at::MyersArgs m;
+			memset(&m, 0, sizeof m);
+			m.npairs = npairs; m.seq = d_seq;
+			m.woff1 = (const long long *)d_woff1; m.woff2 = (const long long *)d_woff2; m.len1 = d_len1; m.len2 = d_len2;
+			m.max_l1 = max_len1; m.max_l2 = max_len2;
+			m.score = d_score; m.end_i = d_end_i; m.end_j = d_end_j; m.state = d_state;
+			m.ap_n = ap_n; m.ap_first = ap_first;
+			m.semi_m2 = 2 * h->m; m.semi_k = (int)k2; m.semi_min2 = (int)std::max<long long>(std::min<long long>(2LL * h->min_score, INT32_MAX), INT32_MIN);
+			m.cand_order = cand; m.cand_count = count;
+			if (!h->d_queue) { HIP_TRY(h, hipMalloc((void **)&h->d_queue, 64)); HIP_TRY(h, hipMemset(h->d_queue, 0, 64)); }
+			HIP_TRY(h, hipMemsetAsync(h->d_queue, 0, 8, stream));
+			m.queue = h->d_queue;
+			const size_t lds = windows(64);
+			int occ = 0;
+			if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, (const void *)ffn, 64, lds) != hipSuccess || occ <= 0) occ = 8;
+			const long long fgrid = std::max(1LL, std::min<long long>((npairs + 63) / 64, (long long)occ * h->ncu));
+			hipLaunchKernelGGL(ffn, dim3((unsigned)fgrid), dim3(64), lds, stream, m);
+			HIP_TRY(h, hipGetLastError());
+			d_order = cand; npairs_dev = count;
+			snprintf(filter_note, sizeof filter_note, "overlap filter (bit-parallel bound, %d words/lane, min score %d) + ", w, h->min_score);
+		}
+	}
+
 	/* the int32 kernels read 2-bit scores from a byte LUT (the packed ones above from a 16-bit one) */
 	if (bits == 2 && !scores_fit_byte(h, mode))
 		return fail(h, AT_ERR_RANGE, "the int32 2-bit kernels need |16*score| <= 127 (m=%d u=%d o=%d): pack the batch with bits=8", h->m, h->u, h->o);
@@ -1022,6 +1088,7 @@ static int align_device(at_handle *h, int mode, int64_t npairs,
 	a.off_bound = L.off_bound; a.ptr_lanes = L.ptr_lanes; a.off_sm = L.off_sm; a.nsm = L.nsm;
 	a.ap_n = ap_n; a.ap_first = ap_first; a.order = d_order;
 	a.only_if = only_if; a.only_val = only_val;
+	a.npairs_dev = npairs_dev;
 	if (kmode == at::K_FITJ) {
 		int rc = ensure_sitemask(h, max_len2, stream);
 		if (rc) return rc;
@@ -1041,6 +1108,10 @@ static int align_device(at_handle *h, int mode, int64_t npairs,
 		HIP_TRY(h, hipFuncSetAttribute((const void *)fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)pl.dyn_lds));
 	hipLaunchKernelGGL(fn, dim3((unsigned)pl.grid), dim3(64), pl.dyn_lds, stream, a);
 	HIP_TRY(h, hipGetLastError());
+	if (filter_note[0]) {
+		const std::string tail = h->cfg;
+		snprintf(h->cfg, sizeof h->cfg, "%s%.200s", filter_note, tail.c_str());
+	}
 	return AT_OK;
 }
 
@@ -1167,7 +1238,7 @@ static int align_host(at_handle *h, int mode, int64_t npairs, const uint8_t *seq
 	else {
 		/* pieces of 4 MB: the staging of one beside the transfer of the one before (copies of 1 MB cross the link at 32 GB/s,
 		 * of 5 MB at 50: tools/pcie_rate.py) */
-		const size_t piece = (size_t)env_ll("AT_HOST_STAGE_PIECE", 4 << 20);
+		const size_t piece = (size_t)std::max<long long>(4096, env_ll("AT_HOST_STAGE_PIECE", 4 << 20));
 		for (size_t at = 0; at < (size_t)blob_bytes; at += piece) {
 			const size_t nb = std::min(piece, (size_t)blob_bytes - at);
 			memcpy((char *)h->hp_blob + at, up_src + at, nb);
@@ -1504,10 +1575,13 @@ static int align_host_mt(at_handle *h, int mode, int64_t npairs, const uint8_t *
 		const int64_t lo = std::min<int64_t>(npairs, c * per), n = std::min<int64_t>(npairs, lo + per) - lo;
 		at_handle *hh = c == 0 ? h : h->kids[(size_t)c - 1];
 		if (n <= 0) return;
-		rcs[(size_t)c] = align_host(hh, mode, n, seq_blob, off1 + lo, len1 + lo, off2 + lo, len2 + lo, want_traceback,
-		                            out_score + lo, out_end_i ? out_end_i + lo : nullptr, out_end_j ? out_end_j + lo : nullptr,
-		                            out_state ? out_state + lo : nullptr, out_ops, ops_off ? ops_off + lo : nullptr,
-		                            out_nops ? out_nops + lo : nullptr, out_r1, out_r2, lo);
+		/* (a chunk runs on a pool thread: an exception that left it would end the process in std::terminate) */
+		rcs[(size_t)c] = guarded(hh, "at_align_batch", [&] {
+			return align_host(hh, mode, n, seq_blob, off1 + lo, len1 + lo, off2 + lo, len2 + lo, want_traceback,
+			                  out_score + lo, out_end_i ? out_end_i + lo : nullptr, out_end_j ? out_end_j + lo : nullptr,
+			                  out_state ? out_state + lo : nullptr, out_ops, ops_off ? ops_off + lo : nullptr,
+			                  out_nops ? out_nops + lo : nullptr, out_r1, out_r2, lo);
+		});
 	};
 	if (!h->pool) h->pool = new HostPool();
 	h->pool->run(nchunks, run);
@@ -1671,10 +1745,12 @@ extern "C" int at_align_allpairs_stream(at_handle *h, int mode, int64_t nreads, 
 	if (rc) return rc;
 	if (npairs == 0) return AT_OK;
 	if (!seq_blob || !off || !len || !fn) return fail(h, AT_ERR_ARG, "NULL argument");
-	ReadSet rs;
-	rc = upload_reads(h, mode, nreads, seq_blob, off, len, &rs);
-	if (rc) return rc;
-	return allpairs_scores(h, mode, nreads, rs, first_pair, npairs, chunk_pairs, fn, user);
+	return guarded(h, "at_align_allpairs_stream", [&] {
+		ReadSet rs;
+		int rc2 = upload_reads(h, mode, nreads, seq_blob, off, len, &rs);
+		if (rc2) return rc2;
+		return allpairs_scores(h, mode, nreads, rs, first_pair, npairs, chunk_pairs, fn, user);
+	});
 }
 
 namespace {
@@ -1755,22 +1831,24 @@ extern "C" int at_align_allpairs(at_handle *h, int mode, int64_t nreads, const u
 	if (!seq_blob || !off || !len || !out_score) return fail(h, AT_ERR_ARG, "NULL argument");
 	const bool tb = want_traceback && mode != AT_MODE_EDIT;
 	if (tb && (!out_ops || !ops_off || !out_nops)) return fail(h, AT_ERR_ARG, "traceback wanted but ops buffers are NULL");
-	ReadSet rs;
-	rc = upload_reads(h, mode, nreads, seq_blob, off, len, &rs);
-	if (rc) return rc;
-	if (!tb) {
-		CopyOut co = {first_pair, out_score, out_end_i, out_end_j, out_state};
-		return allpairs_scores(h, mode, nreads, rs, first_pair, npairs, 0, copy_out_slice, &co);
-	}
-	/* with tracebacks: slices whose ops slots (2 * maxlen bytes per pair) stay below ~1 GiB of device memory */
-	const int64_t per = std::max<int64_t>(1, std::min<int64_t>(1LL << 22, (1LL << 30) / std::max(1, 2 * rs.maxlen)));
-	for (int64_t lo = 0; lo < npairs; lo += per) {
-		const int64_t n = std::min(per, npairs - lo);
-		rc = allpairs_tb_slice(h, mode, nreads, rs, first_pair + lo, n, out_score + lo, out_end_i ? out_end_i + lo : nullptr,
-		                       out_end_j ? out_end_j + lo : nullptr, out_state ? out_state + lo : nullptr, out_ops, ops_off + lo, out_nops + lo);
-		if (rc) return rc;
-	}
-	return AT_OK;
+	return guarded(h, "at_align_allpairs", [&] {
+		ReadSet rs;
+		int rc2 = upload_reads(h, mode, nreads, seq_blob, off, len, &rs);
+		if (rc2) return rc2;
+		if (!tb) {
+			CopyOut co = {first_pair, out_score, out_end_i, out_end_j, out_state};
+			return allpairs_scores(h, mode, nreads, rs, first_pair, npairs, 0, copy_out_slice, &co);
+		}
+		/* with tracebacks: slices whose ops slots (2 * maxlen bytes per pair) stay below ~1 GiB of device memory */
+		const int64_t per = std::max<int64_t>(1, std::min<int64_t>(1LL << 22, (1LL << 30) / std::max(1, 2 * rs.maxlen)));
+		for (int64_t lo = 0; lo < npairs; lo += per) {
+			const int64_t n = std::min(per, npairs - lo);
+			rc2 = allpairs_tb_slice(h, mode, nreads, rs, first_pair + lo, n, out_score + lo, out_end_i ? out_end_i + lo : nullptr,
+			                        out_end_j ? out_end_j + lo : nullptr, out_state ? out_state + lo : nullptr, out_ops, ops_off + lo, out_nops + lo);
+			if (rc2) return rc2;
+		}
+		return (int)AT_OK;
+	});
 }
 
 extern "C" int at_align_batch(at_handle *h, int mode, int64_t npairs, const uint8_t *seq_blob,
@@ -1779,8 +1857,10 @@ extern "C" int at_align_batch(at_handle *h, int mode, int64_t npairs, const uint
                               int32_t *out_score, int32_t *out_end_i, int32_t *out_end_j, int32_t *out_state,
                               uint8_t *out_ops, const int64_t *ops_off, int32_t *out_nops)
 {
-	return align_host_mt(h, mode, npairs, seq_blob, off1, len1, off2, len2, want_traceback, out_score, out_end_i, out_end_j,
-	                     out_state, out_ops, ops_off, out_nops, nullptr, nullptr);
+	return guarded(h, "at_align_batch", [&] {
+		return align_host_mt(h, mode, npairs, seq_blob, off1, len1, off2, len2, want_traceback, out_score, out_end_i, out_end_j,
+		                     out_state, out_ops, ops_off, out_nops, nullptr, nullptr);
+	});
 }
 
 extern "C" int at_align_batch_strings(at_handle *h, int mode, int64_t npairs, const uint8_t *seq_blob,
@@ -1790,6 +1870,8 @@ extern "C" int at_align_batch_strings(at_handle *h, int mode, int64_t npairs, co
 {
 	if (mode == AT_MODE_EDIT) return fail(h, AT_ERR_ARG, "edit has no alignment strings (alignment.h:291)");
 	if (!out_r1 || !out_r2 || !str_off || !out_len) return fail(h, AT_ERR_ARG, "NULL string buffers");
-	return align_host_mt(h, mode, npairs, seq_blob, off1, len1, off2, len2, 1, out_score, out_end_i, out_end_j, out_state,
-	                     nullptr, str_off, out_len, out_r1, out_r2);
+	return guarded(h, "at_align_batch_strings", [&] {
+		return align_host_mt(h, mode, npairs, seq_blob, off1, len1, off2, len2, 1, out_score, out_end_i, out_end_j, out_state,
+		                     nullptr, str_off, out_len, out_r1, out_r2);
+	});
 }

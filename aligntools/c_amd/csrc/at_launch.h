@@ -7,7 +7,8 @@ typedef void (*at_sweep_fn)(const at::SweepArgs);
 typedef void (*at_sweep16_fn)(const at::Sweep16Args, const at::Sweep16Args);   /* (batch, its sliver on 64-lane items) */
 namespace at { struct MyersArgs; }
 typedef void (*at_myers_fn)(const at::MyersArgs);
-at_myers_fn at_pick_myers(int w, int g);   /* w 32-bit words per lane, g lanes per alignment: (1,2,4,8 x 32), (1 x 8), (5,8,16,32 x 1) */
+at_myers_fn at_pick_myers(int w, int g);
+at_myers_fn at_pick_myers_semi(int w);   /* the overlap filter: one alignment per lane, w in {2, 3, 4, 5, 8, 16, 32} */   /* w 32-bit words per lane, g lanes per alignment: (1,2,4,8 x 32), (1 x 8), (5,8,16,32 x 1) */
 
 /* store: 0 = everything in LDS, 1 = s2/boundary in LDS + pointers in the global slot, 2 = everything global */
 at_sweep_fn at_pick32_b2(int kmode, int k, int store, bool tb);

@@ -17,3 +17,9 @@ at_myers_fn at_pick_myers(int w, int g)
 	default: return nullptr;
 	}
 }
+/* the overlap filter (at_myers<W, 1, true>): one alignment per lane, reads of up to 32 * W bases */
+at_myers_fn at_pick_myers_semi(int w)
+{
+	return w == 2 ? at::at_myers<2, 1, true> : w == 3 ? at::at_myers<3, 1, true> : w == 4 ? at::at_myers<4, 1, true> : w == 5 ? at::at_myers<5, 1, true>
+	     : w == 8 ? at::at_myers<8, 1, true> : w == 16 ? at::at_myers<16, 1, true> : w == 32 ? at::at_myers<32, 1, true> : nullptr;
+}

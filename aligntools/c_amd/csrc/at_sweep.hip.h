@@ -88,6 +88,8 @@ struct SweepArgs {
 	 * the int32 kernel behind a device-side check of the batch's shapes and lets the check decide) */
 	const int *only_if;
 	int only_val;
+	/* optional: the number of work items lives on the device (a candidate list a kernel before this one has filled); npairs bounds it */
+	const int *npairs_dev;
 };
 
 extern __shared__ uint32_t at_lds[];
@@ -302,7 +304,8 @@ __global__ __launch_bounds__(64) void at_sweep(const SweepArgs a)
 
 	if (a.only_if && uni(*a.only_if) != a.only_val) return;
 	long long pnext = blockIdx.x;
-	while (pnext < a.npairs) {
+	const long long np = a.npairs_dev ? (long long)imin((int)(a.npairs < 0x7fffffff ? a.npairs : 0x7fffffff), uni(*a.npairs_dev)) : a.npairs;
+	while (pnext < np) {
 		const long long p = a.order ? (long long)a.order[pnext] : pnext;
 		pnext = next_work(a.queue, lane);   /* consumed at the end of this pair: latency hidden */
 		long long ia = p, ib = p;

@@ -125,6 +125,8 @@ static int main_single(int cmd, int argc, char *argv[])
  *     default        records (2k, 2k+1) form pair k
  *     --all-vs-all   the records are reads; every ordered pair a < b is aligned as s1 = read a, s2 = read b (not for fit)
  *     --score-only   no tracebacks: one line per pair (name1, name2, score)
+ *     --min-score T  (overlap --all-vs-all --score-only) only pairs that score at least T are printed; pairs the bit-parallel
+ *                    bound proves below T are not swept at all (at_set_min_score)
  *     --gpus N       one process per GPU: this process starts N workers (itself, with AT_RANK / AT_WORLD / AT_DEVICE /
  *                    AT_COMM_DIR in their environment), rank 0's options are broadcast over RCCL, every rank aligns a
  *                    contiguous share of the pairs on its own GPU, results are gathered over RCCL and rank 0 prints them
@@ -133,7 +135,7 @@ static int main_single(int cmd, int argc, char *argv[])
  * thread -- which also pays the HIP start-up, in the shadow of the first chunks' parsing -- sends each chunk to the GPU
  * and writes its results with one fwrite.  Memory is bounded by the chunks in flight, whatever the size of the file;
  * --all-vs-all keeps the read set and streams slices of the triangle instead (at_align_allpairs_stream). */
-typedef struct { int score_only, all_vs_all, gpus; } batch_flags;
+typedef struct { int score_only, all_vs_all, gpus, min_on, min_score; } batch_flags;
 
 /* linear index p of the strict upper triangle of n x n (row-major) -> (a, b), a < b: closed form + integer correction */
 static void tri_seek(int64_t p, int64_t n, int64_t *a, int64_t *b)
@@ -258,6 +260,12 @@ static int64_t env_i64(const char *name, int64_t dflt)
 	const char *v = getenv(name);
 	return v && *v ? (int64_t)atoll(v) : dflt;
 }
+/* a knob that is a step of a loop or a read size: zero or negative would loop forever or read as end of file */
+static int64_t env_pos(const char *name, int64_t dflt)
+{
+	const int64_t v = env_i64(name, dflt);
+	return v >= 1 ? v : dflt;
+}
 
 static void set_sites(opt_t *opt, const at_chunk *c)
 {
@@ -329,8 +337,8 @@ static int batch_stream_pairs(int cmd, opt_t *opt, int tb, at_reader *rd)
 	pthread_t th;
 	int started = 0, q;
 	size_t total = 0;
-	const size_t first_pairs = (size_t)env_i64("AT_CLI_FIRST_CHUNK", 8192), chunk_pairs = (size_t)env_i64("AT_CLI_CHUNK", 32768);
-	const size_t max_bases = (size_t)env_i64("AT_CLI_CHUNK_BASES", (int64_t)256 << 20);
+	const size_t first_pairs = (size_t)env_pos("AT_CLI_FIRST_CHUNK", 8192), chunk_pairs = (size_t)env_pos("AT_CLI_CHUNK", 32768);
+	const size_t max_bases = (size_t)env_pos("AT_CLI_CHUNK_BASES", (int64_t)256 << 20);
 	memset(pp, 0, sizeof *pp);
 	pthread_mutex_init(&pp->mu, NULL);
 	pthread_cond_init(&pp->cv, NULL);
@@ -377,15 +385,20 @@ static int batch_stream_pairs(int cmd, opt_t *opt, int tb, at_reader *rd)
 }
 
 /* ---- everything else keeps the whole record set: --all-vs-all, and the ranks of --gpus N ---- */
-typedef struct { const at_chunk *c; int64_t a, b, nrec; int is_edit; tbuf out; } ava_print;
+typedef struct { const at_chunk *c; int64_t a, b, nrec; int is_edit; tbuf out; int min_on, min_score; int32_t *keep; int64_t keep_first; } ava_print;
 
 static int print_slice(void *user, int64_t first, int64_t n, const int32_t *score, const int32_t *ei, const int32_t *ej, const int32_t *st)
 {
 	ava_print *ap = (ava_print *)user;
 	int64_t k;
 	(void)first; (void)ei; (void)ej; (void)st;
+	if (ap->keep) {                     /* a rank of many: its share of the scores, for the gather */
+		memcpy(ap->keep + (first - ap->keep_first), score, (size_t)n * 4);
+		return 0;
+	}
 	for (k = 0; k < n; ++k) {
-		tb_pair(&ap->out, ap->c->names + ap->c->name_off[ap->a], ap->c->names + ap->c->name_off[ap->b], score[k], ap->is_edit, NULL, NULL, 0);
+		if (!ap->min_on || score[k] >= ap->min_score)   /* (a pair the filter stopped carries an upper bound below the threshold) */
+			tb_pair(&ap->out, ap->c->names + ap->c->name_off[ap->a], ap->c->names + ap->c->name_off[ap->b], score[k], ap->is_edit, NULL, NULL, 0);
 		TRI_NEXT(ap->a, ap->b, ap->nrec);
 		if (ap->out.l > ((size_t)8 << 20)) tb_flush(&ap->out);
 	}
@@ -409,7 +422,7 @@ static int batch_worker(int cmd, opt_t *opt, const batch_flags *bf, const char *
 	const int comm = world > 1 || getenv("AT_COMM_FORCE_RCCL") != NULL;   /* (the latter: the RCCL calls at world size 1, for tests) */
 	const int mode = cmd == C_GLOBAL ? AT_MODE_GLOBAL : cmd == C_LOCAL ? AT_MODE_LOCAL : cmd == C_FIT ? AT_MODE_FIT
 	               : cmd == C_OVERLAP ? AT_MODE_OVERLAP : AT_MODE_EDIT;
-	const int64_t chunk_pairs = env_i64("AT_CLI_CHUNK", 32768) * 8;
+	const int64_t chunk_pairs = env_pos("AT_CLI_CHUNK", 32768) * 8;
 	if (!rd) die("Can't open %s\n", fname);
 	if (bf->all_vs_all && cmd == C_FIT) die("--all-vs-all: fit needs ordered pairs (first sequence shorter than the second)");
 	if (!bf->all_vs_all && !comm) {
@@ -444,6 +457,7 @@ static int batch_worker(int cmd, opt_t *opt, const batch_flags *bf, const char *
 		if (rc == AT_OK) rc = at_comm_broadcast_scoring(h);      /* rank 0's options are everybody's */
 		trace("comm: scoring broadcast done", rc);
 	}
+ 	if (rc == AT_OK && bf->min_on) rc = at_set_min_score(h, 1, bf->min_score);
 	if (rc != AT_OK) die("%s", at_last_error(h));
 	if (bf->all_vs_all) {
 		int64_t k;
@@ -455,6 +469,7 @@ static int batch_worker(int cmd, opt_t *opt, const batch_flags *bf, const char *
 		ava_print ap;
 		memset(&ap, 0, sizeof ap);
 		ap.c = &c; ap.nrec = nrec; ap.is_edit = cmd == C_EDIT; ap.a = 0; ap.b = 1;
+		ap.min_on = bf->min_on; ap.min_score = bf->min_score;
 		rc = at_align_allpairs_stream(h, mode, nrec, c.blob, roff, rlen, 0, npairs, env_i64("AT_CLI_CHUNK", 0), print_slice, &ap);
 		if (rc != AT_OK) die("%s", at_last_error(h));
 		free(ap.out.s);
@@ -464,7 +479,17 @@ static int batch_worker(int cmd, opt_t *opt, const batch_flags *bf, const char *
 		tbuf pay = {NULL, 0, 0};
 		int64_t s0, k;
 		if (bf->all_vs_all && hi > lo) tri_seek(lo, nrec, &a, &b);
-		for (s0 = lo; s0 < hi; s0 += chunk_pairs) {
+		const int streamed = bf->all_vs_all && !tb && comm;
+		if (streamed && hi > lo) {
+			/* this rank's share of the triangle's scores: the reads go up once, the slices land in myscore (one
+			 * at_align_allpairs call per slice uploaded and packed the whole read set again every time) */
+			ava_print ap;
+			memset(&ap, 0, sizeof ap);
+			ap.keep = myscore; ap.keep_first = lo;
+			rc = at_align_allpairs_stream(h, mode, nrec, c.blob, roff, rlen, lo, hi - lo, env_i64("AT_CLI_CHUNK", 0), print_slice, &ap);
+			if (rc != AT_OK) die("%s", at_last_error(h));
+		}
+		for (s0 = lo; s0 < hi && !streamed; s0 += chunk_pairs) {
 			const int64_t n = hi - s0 < chunk_pairs ? hi - s0 : chunk_pairs;
 			int64_t a0 = a, b0 = b;
 			slice_reserve(&w, n);
@@ -483,6 +508,7 @@ static int batch_worker(int cmd, opt_t *opt, const batch_flags *bf, const char *
 			if (!comm) {
 				for (k = 0; k < n; ++k) {
 					const int64_t ra = bf->all_vs_all ? a0 : 2 * (s0 + k), rb = bf->all_vs_all ? b0 : 2 * (s0 + k) + 1;
+					if (!bf->min_on || tb || w.score[k] >= bf->min_score)
 					tb_pair(&out, c.names + c.name_off[ra], c.names + c.name_off[rb], w.score[k], cmd == C_EDIT,
 					        tb ? w.r1 + w.slot[k] : NULL, tb ? w.r2 + w.slot[k] : NULL, tb ? (size_t)w.nops[k] : 0);
 					if (bf->all_vs_all) TRI_NEXT(a0, b0, nrec);
@@ -522,7 +548,8 @@ static int batch_worker(int cmd, opt_t *opt, const batch_flags *bf, const char *
 					const int64_t ra = bf->all_vs_all ? a : 2 * q, rb = bf->all_vs_all ? b : 2 * q + 1;
 					const char *x = tb ? allpay + o : NULL;
 					const size_t xl = tb ? strlen(x) : 0;
-					tb_pair(&out, c.names + c.name_off[ra], c.names + c.name_off[rb], allscore[q], cmd == C_EDIT, x, tb ? x + xl + 1 : NULL, xl);
+					if (!bf->min_on || tb || allscore[q] >= bf->min_score)
+						tb_pair(&out, c.names + c.name_off[ra], c.names + c.name_off[rb], allscore[q], cmd == C_EDIT, x, tb ? x + xl + 1 : NULL, xl);
 					if (tb) o += 2 * ((int64_t)xl + 1);
 					if (bf->all_vs_all) TRI_NEXT(a, b, nrec);
 					if (out.l > ((size_t)8 << 20)) tb_flush(&out);
@@ -599,20 +626,24 @@ static int main_batch(int argc, char *argv[], char *argv0)
 {
 	int cmd = -1, k, n = 0;
 	opt_t *opt = init_opt();
-	batch_flags bf = {0, 0, 1};
+	batch_flags bf = {0, 0, 1, 0, 0};
 	char **av = (char **)at_xmalloc((size_t)(argc + 1) * sizeof(char *));
-	const char *usage_line = "Usage:   alignTools batch <global|local|fit|overlap|edit> [options] [--score-only] [--all-vs-all] [--gpus N] <pairs.fa>\n";
+	const char *usage_line = "Usage:   alignTools batch <global|local|fit|overlap|edit> [options] [--score-only] [--all-vs-all] [--min-score T] [--gpus N] <pairs.fa>\n";
 	/* the long flags of the extension are taken out before getopt sees the reference's short options */
 	for (k = 0; k < argc; ++k) {
 		if (strcmp(argv[k], "--score-only") == 0) bf.score_only = 1;
 		else if (strcmp(argv[k], "--all-vs-all") == 0) bf.all_vs_all = 1;
 		else if (strcmp(argv[k], "--gpus") == 0 && k + 1 < argc) bf.gpus = atoi(argv[++k]);
+		else if (strcmp(argv[k], "--min-score") == 0 && k + 1 < argc) { bf.min_on = 1; bf.min_score = atoi(argv[++k]); }
 		else av[n++] = argv[k];
 	}
 	av[n] = NULL;
 	if (n < 2 || bf.gpus < 1 || bf.gpus > 64) { fprintf(stderr, "%s", usage_line); free(opt); free(av); return 1; }
 	for (k = 0; k < 5; ++k) if (strcmp(av[1], cmd_name[k]) == 0) cmd = k;
 	if (cmd < 0) { fprintf(stderr, "[main] unrecognized command '%s'\n", av[1]); free(opt); free(av); return 1; }
+	if (bf.min_on && !(cmd == C_OVERLAP && bf.all_vs_all && bf.score_only)) {
+		fprintf(stderr, "--min-score goes with `batch overlap --all-vs-all --score-only`\n%s", usage_line); free(opt); free(av); return 1;
+	}
 	if (parse_opts(cmd, n - 1, av + 1, opt)) { free(opt); free(av); return 1; }
 	if (optind + 1 > n - 1) { cmd_usage(cmd, opt); free(opt); free(av); return 1; }
 	if (bf.gpus > 1 && !getenv("AT_RANK")) {        /* the launcher: never touches a GPU itself */
@@ -634,7 +665,8 @@ static int leave(int ret)
 {
 	const char *v = getenv("AT_FAST_EXIT");
 	if (!at_host_handle_exists() || (v && *v == '0')) return ret;
-	fflush(stdout); fflush(stderr);
+	if ((fflush(stdout) != 0 || ferror(stdout)) && ret == 0) ret = 1;   /* (a final write that failed must not leave with 0) */
+	fflush(stderr);
 	_exit(ret);
 }
 

@@ -186,11 +186,14 @@ size_t at_reader_read(at_reader *r, size_t max_records, size_t max_bases, at_chu
 		}
 		/* header line */
 		{
-			(void)get_line(r, &p, &n, &any);
+			const int nl_ended = get_line(r, &p, &n, &any);
 			if (!any) return added;                         /* the file ends right behind the marker: no record (kseq -1) */
 			for (k = 0; k < n && !is_space(p[k]); ++k) {}
 			name_at = put_text(&c->names, &c->names_len, &c->names_cap, p, k);
-			if (k < n) {                                     /* a whitespace other than the line's newline: the rest is the comment */
+			/* a whitespace other than the line's newline: the rest is the comment.  When the FILE ends right behind that whitespace
+			 * kseq's ks_getuntil(comment) reads nothing, returns -1 and leaves the comment buffer as it was -- the previous
+			 * record's text, or none (kseq.h:189-229) */
+			if (k < n && (k + 1 < n || nl_ended)) {
 				size_t cl = n - k - 1;
 				if (cl > 1 && p[n - 1] == '\r') --cl;
 				grow_bytes((void **)&r->comment, &r->comment_cap, cl + 1);
@@ -206,11 +209,13 @@ size_t at_reader_read(at_reader *r, size_t max_records, size_t max_bases, at_chu
 			if (c0 == '>' || c0 == '@' || c0 == '+') { ++r->begin; r->last = c0; break; }
 			if (c0 == '\n') { ++r->begin; continue; }
 			{
-				(void)get_line(r, &p, &n, &any);
+				const int nl_ended = get_line(r, &p, &n, &any);
 				grow_bytes((void **)&c->blob, &c->blob_cap, seq_at + seq_len + n + 1);
 				memcpy(c->blob + seq_at + seq_len, p, n);
 				seq_len += n;
-				if (seq_len > 1 && c->blob[seq_at + seq_len - 1] == '\r') --seq_len;
+				/* kseq takes a line's first byte with ks_getc and the rest with ks_getuntil2, which drops a trailing '\r' -- unless it
+				 * read nothing and the file is over (it returns before that, kseq.h:141): a lone last byte '\r' stays */
+				if (n + (size_t)nl_ended >= 2 && seq_len > 1 && c->blob[seq_at + seq_len - 1] == '\r') --seq_len;
 			}
 		}
 		if (r->last == '+') {

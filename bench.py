@@ -220,6 +220,9 @@ def main():
                     help="N > 1: steps whose results travel in one collective (fixed-size results and CIGAR payload each)")
     ap.add_argument("--no-cigar-gather", action="store_true", help="N > 1: gather only the fixed-size results (diagnostic)")
     ap.add_argument("--no-gather", action="store_true", help="N > 1: no per-step collective at all (diagnostic)")
+    ap.add_argument("--min-score", type=int, default=None,
+                    help="C5all / C5full: all-vs-all overlap scores with a threshold (at_set_min_score): pairs proven to score below it by the "
+                         "bit-parallel bound are not swept, the others are exact")
     ap.add_argument("--no-render", action="store_true",
                     help="stop at the op codes (CIGARs): do not also turn them into the reference's two gapped strings on the GPU "
                          "inside every step (at_render_batch_device)")
@@ -296,12 +299,15 @@ def main():
     scl = sc.cpu().tolist()
     m, u, o, e, j, uj, ns = scl[:7]
     site_list = st.cpu().tolist()[:ns]
+    allpairs_w = args.workload in ("C5all", "C5full")
     S = max(1, args.streams)
     LAG = S                                          # the CIGAR payload of step k is sent when its stream comes round again
     NB = S + 2                                       # buffer sets, used in turn
     als = [A.Aligner(local_rank) for _ in range(S)]  # one handle (workspace, work queue) per stream
     for x in als:
         x.set_scoring(m, u, o, e, j, bool(uj), site_list)
+        if args.min_score is not None and allpairs_w:
+            x.set_min_score(args.min_score)
     al = als[0]
     streams = [torch.cuda.Stream(device=dev) for _ in range(S)] if S > 1 else [torch.cuda.current_stream()]
 
@@ -617,7 +623,9 @@ def main():
             "config": {"workload": "%s: %s %s, %d x (%dx%d bp) pairs per GPU, uniform ACGT, m=%d u=%d o=%d e=%d%s, "
                                    "%s" % (args.workload, mode, "linear-gap" if mode == "overlap" else "unit-gap" if mode == "edit" else "affine-gap", pairs, l1, l2,
                                            m, u, o, e, " j=%d -s" % j if uj else "",
-                                           ("scores+tracebacks+rendered strings" if rend else "scores+tracebacks") if tb else "scores only"),
+                                           ("scores+tracebacks+rendered strings" if rend else "scores+tracebacks") if tb else
+                                           ("scores of the pairs that may reach %d (the others: an upper bound below it)" % args.min_score
+                                            if (args.min_score is not None and allpairs_w) else "scores only")),
                        "pairs_per_gpu": pairs, "l1": l1, "l2": l2, "bits_per_base": bits, "kernel_config": al.last_config,
                        "streams": S,
                        "parallelism": "pairs sharded over %d GPU(s), one process per GPU" % world},

@@ -159,6 +159,18 @@ int at_align_allpairs(at_handle *h, int mode, int64_t nreads,
                       uint8_t *out_ops, const int64_t *ops_off, int32_t *out_nops);
 
 /*
+ * A score threshold for all-vs-all overlap SCORES (at_align_allpairs_device / at_align_allpairs / at_align_allpairs_stream with
+ * AT_MODE_OVERLAP and no tracebacks; reads of up to 1 024 bases, ACGT): with enabled != 0 a pair whose score -- the value of
+ * align_overlap, alignment.h:926-964 -- is PROVEN to lie below min_score is not swept: its state is 0, its score an upper bound
+ * (< min_score) and its end_j 0.  Every other pair (state 2) carries the exact results as without the threshold, whether its score
+ * reaches min_score or not.  The proof is an upper bound from the bit-parallel edit distance of the pair with a free start in s1
+ * (csrc/at_myers.hip.h): 2 score <= 2 m b - (2 c - m) D'(l1, b), c = min(m - u, m / 2 - o); it needs m >= 0 and 2 c > m (the default
+ * scoring of `alignTools overlap`, m = 1 u = -2 o = -5, gives 2 b - 5 D'), otherwise every pair is swept.  enabled = 0 (the default)
+ * sweeps every pair.
+ */
+int at_set_min_score(at_handle *h, int enabled, int32_t min_score);
+
+/*
  * The same sweep with bounded memory, for triangles too large to hold (C5: 50 000 reads = 1.25e9 pairs = 20 GB of
  * results): scores and end cells only, the triangle cut into slices of at most chunk_pairs pairs (<= 0: 4 Mi); `fn`
  * is called once per slice, in pair order, on the calling thread, while the GPU already sweeps the next slice.  The

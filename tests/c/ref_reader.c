@@ -70,7 +70,7 @@ static int sgetuntil(stream *s, int line, sbuf *b, int append, int *got)
 {
 	int c;
 	*got = 0;
-	if (!append) { b->l = 0; if (b->s) b->s[0] = 0; }
+	if (!append) b->l = 0;
 	for (;;) {
 		c = sgetc(s);
 		if (c < 0) break;
@@ -78,7 +78,11 @@ static int sgetuntil(stream *s, int line, sbuf *b, int append, int *got)
 		if (line ? c == '\n' : isspace(c)) break;
 		sput(b, c);
 	}
+	/* nothing read and the file is over: ks_getuntil2 returns -1 BEFORE it terminates the string (kseq.h:98-99, 141) -- the length
+	 * is 0 but the text, which is what kstring_read looks at (alignment.h:236), is the previous record's, or none */
+	if (!*got && c < 0) return c;
 	if (!b->s) sput(b, 0), b->l = 0;
+	b->s[b->l] = 0;
 	if (line && b->l > 1 && b->s[b->l - 1] == '\r') b->s[--b->l] = 0;
 	return c;
 }

@@ -1559,3 +1559,90 @@ def test_two_pass_default_routing(al, monkeypatch):
         assert ("two-pass" in al.last_config) == want, (l1, al.last_config)
         al.align_batch("global", pairs, traceback=False, render=False)
         assert "two-pass" not in al.last_config
+
+
+@pytest.mark.parametrize("shape", [(1000, 1000, 260), (300, 1000, 300), (150, 160, 500), (40, 64, 400), (500, 512, 200)])
+def test_overlap_threshold_filter(al, shape):
+    """All-vs-all overlap scores with a threshold (at_set_min_score; at_myers.hip.h, SEMI): pairs whose score is proven below T by the
+    bit-parallel bound are not swept.  Against the unthresholded sweep of the same triangle: every pair the filter let through
+    (state 2) carries the exact score and end cell; every pair it stopped (state 0) really scores below T, and the bound it reports
+    is one; unrelated reads are stopped, planted overlaps are not.  Read sets of mixed lengths, every word class of the filter."""
+    import torch
+    import aligntools.c_amd as A
+    lo, hi, n = shape
+    rng = random.Random(lo * 31 + hi)
+    reads = ["".join(rng.choice("ACGT") for _ in range(rng.randint(lo, hi))) for _ in range(n)]
+    planted = []
+    for k in range(0, n - 1, 7):            # read k + 1 starts with (a noisy copy of) the end of read k
+        a = reads[k]
+        ov = rng.randint(min(20, len(a)), max(min(20, len(a)), min(len(a), hi) * 3 // 4))
+        piece = list(a[len(a) - ov:])
+        for _ in range(ov // 25):
+            q = rng.randrange(len(piece))
+            r = rng.random()
+            if r < 0.6:
+                piece[q] = rng.choice("ACGT")
+            elif r < 0.8 and len(piece) > 1:
+                del piece[q]
+            else:
+                piece.insert(q, rng.choice("ACGT"))
+        b = ("".join(piece) + reads[k + 1])[:max(lo, min(hi, len(reads[k + 1])))]
+        reads[k + 1] = b
+        planted.append((k, k + 1))
+    words, woff, _w2, lens, _l2, bits = A.pack_pairs([(r.encode(), b"") for r in reads])
+    assert bits == 2
+    dev = torch.device("cuda", 0)
+    d_words = torch.from_numpy(words.view(np.int32)).to(dev)
+    d_woff = torch.from_numpy(woff).to(dev)
+    d_len = torch.from_numpy(lens).to(dev)
+    total = n * (n - 1) // 2
+    maxl = int(lens.max())
+    stream = torch.cuda.current_stream().cuda_stream
+
+    def sweep():
+        res = torch.full((4, total), -7, dtype=torch.int32, device=dev)
+        al.align_allpairs_device(A.MODES["overlap"], n, d_words.data_ptr(), bits, d_woff.data_ptr(), d_len.data_ptr(), maxl, 0, total, False,
+                                 res[0].data_ptr(), res[1].data_ptr(), res[2].data_ptr(), res[3].data_ptr(), 0, 0, 0, stream)
+        torch.cuda.synchronize()
+        return res.cpu().numpy()
+
+    for sc in ((1, -2, -5, -1), (2, -3, -4, -1)):
+        al.set_scoring(*sc)
+        al.set_min_score(None)
+        exact = sweep()
+        assert "filter" not in al.last_config
+        for T in (12, 30, 10 ** 6):
+            al.set_min_score(T)
+            try:
+                got = sweep()
+            finally:
+                al.set_min_score(None)
+            assert "overlap filter" in al.last_config, al.last_config
+            swept = got[3] == 2
+            assert ((got[3] == 0) | swept).all()
+            for row in range(3):
+                assert (got[row][swept] == exact[row][swept]).all(), (sc, T, row)
+            assert (exact[0][~swept] < T).all(), (sc, T)                   # nothing that reaches T was stopped
+            assert (got[0][~swept] >= exact[0][~swept]).all() and (got[0][~swept] < T).all()   # ... and what it reports is a bound
+            assert (exact[0][swept] >= T).sum() == (exact[0] >= T).sum()
+            if T == 30 and sc == (1, -2, -5, -1) and lo >= 150:
+                assert swept.mean() < 0.05, swept.mean()                   # unrelated reads are stopped by the bound
+            if T == 10 ** 6:
+                assert not swept.any()
+        # the planted overlaps score high and are swept
+        al.set_min_score(20)
+        try:
+            got = sweep()
+        finally:
+            al.set_min_score(None)
+        t_of = lambda a, b: a * n - a * (a + 1) // 2 + (b - a - 1)
+        hits = [p for p in planted if exact[0][t_of(*p)] >= 20]
+        assert len(hits) >= len(planted) // 2
+        for p in hits:
+            assert got[3][t_of(*p)] == 2
+    # the oracle on the planted pairs (default scoring: what `alignTools overlap` can reach)
+    al.set_scoring(1, -2, -5, -1)
+    exact = sweep()
+    for a, b in planted[:12]:
+        r = O.align(O.OVERLAP, reads[a], reads[b], 1, -2, -5, -1)
+        assert (int(exact[0][t_of(a, b)]), int(exact[2][t_of(a, b)])) == (r["score"], r["end_j"]), (a, b)

@@ -7,9 +7,10 @@
  * bring their own RCCL, like PyTorch) never see it.  The rendezvous is a directory the launcher creates (AT_COMM_DIR):
  * rank 0 writes the ncclUniqueId there, the other ranks wait for it.
  *
- * AT_COMM=files replaces RCCL by files in that directory.  It exists to rehearse the N > 1 logic of the host with
- * several ranks on ONE card (RCCL refuses two ranks on one device), the way bench.py's --backend gloo does; it is not a
- * product path and moves no data over xGMI.
+ * AT_RCCL_LIB names another library to load in RCCL's place (default: librccl.so.1, then librccl.so).  The tests use it to
+ * rehearse the N > 1 logic of the host with several ranks on ONE card -- RCCL refuses two ranks on one device -- against a
+ * stand-in that implements the five entry points over files (tests/c/fake_rccl_files.c, built by the tests, never shipped in
+ * this library: round 3 had that transport compiled in here as AT_COMM=files).
  */
 #include "../../../include/aligntools_hip.h"
 
@@ -67,9 +68,7 @@ static_assert(std::is_same<decltype(&ncclGetErrorString), const char *(*)(ncclRe
 
 struct Comm {
 	int rank = 0, world = 1;
-	bool files = false;
 	std::string dir;
-	long seq = 0;                       /* files transport: collective counter */
 	void *lib = nullptr, *comm = nullptr;
 	fn_bcast bcast = nullptr; fn_allgather allgather = nullptr; fn_destroy destroy = nullptr; fn_errstr errstr = nullptr;
 	hipStream_t stream = nullptr;
@@ -119,19 +118,6 @@ int dev_buf(at_handle *h, Comm *c, size_t need)
 int allgather_fixed(at_handle *h, Comm *c, const void *mine, size_t n, void *all)
 {
 	if (c->world == 1 && !c->comm) { memcpy(all, mine, n); return AT_OK; }
-	if (c->files) {
-		const long q = c->seq++;
-		char name[64];
-		snprintf(name, sizeof name, "/g%ld_%d", q, c->rank);
-		if (!write_file_atomically(c->dir + name, mine, n)) return at_comm_fail(h, AT_ERR_ARG, "at_comm(files): cannot write into AT_COMM_DIR");
-		for (int r = 0; r < c->world; ++r) {
-			std::vector<char> d;
-			snprintf(name, sizeof name, "/g%ld_%d", q, r);
-			if (!wait_for_file(c->dir + name, d, 600.0) || d.size() != n) return at_comm_fail(h, AT_ERR_ARG, "at_comm(files): a rank did not deliver its part");
-			memcpy((char *)all + (size_t)r * n, d.data(), n);
-		}
-		return AT_OK;
-	}
 	const size_t pad = (n + 15) & ~(size_t)15;
 	int rc = dev_buf(h, c, pad * ((size_t)c->world + 1));
 	if (rc) return rc;
@@ -154,17 +140,21 @@ static int comm_init(at_handle *h, int rank, int world, const char *dir)
 	if (*at_comm_slot(h)) return at_comm_fail(h, AT_ERR_ARG, "at_comm_init: this handle already has a communicator (at_comm_destroy first)");
 	Comm *c = new Comm();
 	c->rank = rank; c->world = world; c->dir = dir;
-	const char *mode = getenv("AT_COMM");
-	c->files = mode && strcmp(mode, "files") == 0;
 	*at_comm_slot(h) = c;
 	/* (a world of one needs no collective; AT_COMM_FORCE_RCCL=1 builds the communicator anyway, so that the RCCL branch --
 	 * dlopen, ncclCommInitRank, ncclBroadcast, ncclAllGather -- can be exercised on a one-GPU box) */
-	if (c->files || (world == 1 && !getenv("AT_COMM_FORCE_RCCL"))) return AT_OK;
+	if (world == 1 && !getenv("AT_COMM_FORCE_RCCL")) return AT_OK;
 	if (hipSetDevice(at_handle_device(h)) != hipSuccess || hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess)
 		return at_comm_fail(h, AT_ERR_NODEVICE, "at_comm_init: no stream on this rank's device");
-	c->lib = dlopen("librccl.so.1", RTLD_NOW | RTLD_LOCAL);
-	if (!c->lib) c->lib = dlopen("librccl.so", RTLD_NOW | RTLD_LOCAL);
-	if (!c->lib) return at_comm_fail(h, AT_ERR_NODEVICE, "at_comm_init: librccl.so not found (needed for --gpus N > 1)");
+	const char *named = getenv("AT_RCCL_LIB");
+	if (named && *named) {
+		c->lib = dlopen(named, RTLD_NOW | RTLD_LOCAL);
+		if (!c->lib) return at_comm_fail(h, AT_ERR_NODEVICE, "at_comm_init: cannot load the library AT_RCCL_LIB names");
+	} else {
+		c->lib = dlopen("librccl.so.1", RTLD_NOW | RTLD_LOCAL);
+		if (!c->lib) c->lib = dlopen("librccl.so", RTLD_NOW | RTLD_LOCAL);
+		if (!c->lib) return at_comm_fail(h, AT_ERR_NODEVICE, "at_comm_init: librccl.so not found (needed for --gpus N > 1)");
+	}
 	fn_uid get_uid = (fn_uid)dlsym(c->lib, "ncclGetUniqueId");
 	fn_init init = (fn_init)dlsym(c->lib, "ncclCommInitRank");
 	c->bcast = (fn_bcast)dlsym(c->lib, "ncclBroadcast");
@@ -206,22 +196,7 @@ static int comm_broadcast_scoring(at_handle *h)
 	at_get_scoring(h, v, &sites);                 /* v[0..5] = m,u,o,e,j,use_jump, v[6] = nsites */
 	std::vector<int> st(sites, sites + v[6]);
 	if (c->world > 1 || c->comm) {
-		if (c->files) {
-			const long q = c->seq++;
-			char name[64];
-			snprintf(name, sizeof name, "/b%ld", q);
-			if (c->rank == 0) {
-				std::vector<int> blob(v, v + 8);
-				blob.insert(blob.end(), st.begin(), st.end());
-				if (!write_file_atomically(c->dir + name, blob.data(), blob.size() * 4)) return at_comm_fail(h, AT_ERR_ARG, "at_comm(files): cannot write into AT_COMM_DIR");
-			} else {
-				std::vector<char> d;
-				if (!wait_for_file(c->dir + name, d, 600.0) || d.size() < 32) return at_comm_fail(h, AT_ERR_ARG, "at_comm(files): no scoring block from rank 0");
-				memcpy(v, d.data(), 32);
-				if (v[6] < 0 || d.size() < 32 + (size_t)v[6] * 4) return at_comm_fail(h, AT_ERR_ARG, "at_comm(files): truncated scoring block");
-				st.assign((const int *)(d.data() + 32), (const int *)(d.data() + 32) + v[6]);
-			}
-		} else {
+		{
 			int rc = dev_buf(h, c, 64);
 			if (rc) return rc;
 			if (hipMemcpyAsync(c->d_buf, v, 32, hipMemcpyHostToDevice, c->stream) != hipSuccess) return at_comm_fail(h, AT_ERR_NODEVICE, "at_comm: upload failed");

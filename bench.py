@@ -27,7 +27,7 @@ Steps alternate over `--streams` HIP streams (default 3), each with its own
 handle (workspace, work queue) and output buffers, so up to three launches are
 in flight: the SIMDs that the draining tail of step k leaves idle are taken by
 step k+1 (one launch alone spends 17 % of its time in its first and last round,
-DESIGN.md 3.7).  Every step still computes its whole batch; `--streams 1` runs
+profiles/LOG.md C).  Every step still computes its whole batch; `--streams 1` runs
 them strictly one after the other.
 
 Prints ONE JSON line (rank 0).  `roofline` prices the sweep kernel against the
@@ -47,7 +47,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0   # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
-PROFILE_ROUND = "r03"   # profiles/<round>/traffic_<workload>.json, valu_issue.json: the counters the roofline is priced with
+PROFILE_ROUND = "r04"   # profiles/<round>/traffic_<workload>.json, valu_issue.json: the counters the roofline is priced with
 
 
 def _traffic(workload, tb):
@@ -75,7 +75,7 @@ def valu_roofline(workload, pairs, tb, kernel_config, steps, elapsed, cells_per_
     `insts_per_alignment`, with the scores-only kernel's figures beside them (the instructions a traceback costs)."""
     prof = _traffic(workload, tb)
     vi = vi_src = None
-    for rnd in (PROFILE_ROUND, "r02"):   # the issue rates are a property of the chip: measured in round 2, measured again when a round re-runs tools/valu_issue.hip
+    for rnd in (PROFILE_ROUND, "r03", "r02"):   # the issue rates are a property of the chip: measured in round 2, measured again when a round re-runs tools/valu_issue.hip
         try:
             vi_src = "profiles/%s/valu_issue.json" % rnd
             vi = json.load(open(os.path.join(ROOT, vi_src)))
@@ -117,6 +117,12 @@ def valu_roofline(workload, pairs, tb, kernel_config, steps, elapsed, cells_per_
                "MI355X_MICROARCH.md documents the 2-cycle class only)", clock_ghz=ghz, simds=simds,
                insts_per_alignment=insts / pairs, insts_per_cell=insts / (pairs * cells_per_pair), kernel_source_sha16=src_sha,
                source="profiles/%s/traffic_%s%s.json + %s" % (PROFILE_ROUND, workload, "" if tb else "_scores", vi_src))
+    # the same class from the production kernel's own counters: cycles the launch was resident on the chip (GRBM_GUI_ACTIVE, summed
+    # over the 8 XCDs) per VALU instruction of one SIMD -- what the microbenchmark's 4-cycle class predicts if the SIMDs issue all the time
+    sq = prof.get("sq_counters_per_launch") or {}
+    if sq.get("GRBM_GUI_ACTIVE") and insts:
+        out["cycles_per_inst_from_counters"] = (sq["GRBM_GUI_ACTIVE"] / 8.0) / (insts / float(simds))
+        out["cycles_per_inst_from_counters_source"] = "GRBM_GUI_ACTIVE / 8 XCDs over SQ_INSTS_VALU / %d SIMDs of the profiled launch (one launch at a time, --streams 1)" % simds
     other = _traffic(workload, not tb)
     oi = ((other or {}).get("sq_counters_per_launch") or {}).get("SQ_INSTS_VALU")
     if oi and other.get("kernel_source_sha16") == src_sha and other.get("pairs") == pairs:
@@ -610,7 +616,8 @@ def main():
     # algorithmic HBM bytes of one launch on one GPU
     bytes_in = words_nbytes + pairs * (8 + 8 + 4 + 4) + (pairs * 8 if tb else 0)
     bytes_out = pairs * 16 + (pairs * 4 + int(nops.sum()) if tb else 0)
-    achieved = (bytes_in + bytes_out) / (kern_avg_ms * 1e-3) / 1e9
+    step_s = elapsed / max(1, args.steps)            # (launches overlap: a launch's own first-to-last-wave time is not a per-step figure)
+    achieved = (bytes_in + bytes_out) / step_s / 1e9
     valu, traffic = valu_roofline(args.workload, pairs, tb, al.last_config, args.steps, elapsed, float(l1) * l2, A.kernel_source_sha16())
 
     if rank == 0:
@@ -636,10 +643,13 @@ def main():
                              kernel_avg_ms=kern_avg_ms, kernel_min_ms=kern_ms[0], kernel_alone_ms=kern_iso_ms, launches_in_flight=S,
                              host_issue_ms_per_step=(t_issued - t0) * 1e3 / max(1, args.steps),
                              gcups_one_launch_at_a_time=cells_per_step / world / (kern_iso_ms * 1e-3) / 1e9,
-                             # the HBM view BASELINE.json asks for: ALGORITHMIC bytes of a launch over its HIP-event duration
+                             # the HBM view BASELINE.json asks for, both ways: the ALGORITHMIC bytes of a launch over the time per step, and the
+                             # bytes the chip really moved (PMC FETCH_SIZE x 2 + WRITE_SIZE of the same kernel configuration) over it
                              hbm={"achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                                  "achieved_aggregate": (bytes_in + bytes_out) * args.steps / elapsed / 1e9,
+                                  "achieved_counter": (traffic / step_s / 1e9) if traffic else None,
+                                  "frac_counter": (traffic / step_s / 1e9 / HBM_PEAK_GBS) if traffic else None,
                                   "algorithmic_bytes_per_launch": bytes_in + bytes_out,
+                                  "counter_bytes_per_launch": traffic,
                                   "traffic_over_algorithmic": (traffic / float(bytes_in + bytes_out)) if traffic else None}),
             "cpu_baseline": base,
         }

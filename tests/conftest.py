@@ -23,3 +23,17 @@ def load_golden(name):
 @pytest.fixture(scope="session")
 def golden():
     return load_golden
+
+
+@pytest.fixture(scope="session")
+def fake_rccl(tmp_path_factory):
+    """Path of a stand-in for librccl.so whose collectives go through files in the job's rendezvous directory
+    (tests/c/fake_rccl_files.c): AT_RCCL_LIB=<this> lets several ranks share the test box's one card."""
+    import subprocess
+    d = tmp_path_factory.mktemp("fake_rccl")
+    so = str(d / "libfake_rccl.so")
+    rocm = os.environ.get("ROCM_PATH", "/opt/rocm")
+    subprocess.run(["gcc", "-shared", "-fPIC", "-O1", "-std=c99", "-I" + os.path.join(rocm, "include"),
+                    os.path.join(ROOT, "tests", "c", "fake_rccl_files.c"), "-o", so, "-L" + os.path.join(rocm, "lib"), "-lamdhip64",
+                    "-Wl,-rpath," + os.path.join(rocm, "lib")], check=True)
+    return so

@@ -152,16 +152,17 @@ def test_cli_batch_score_only_and_all_vs_all(built, tmp_path):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("flags", [[], ["--score-only"], ["--all-vs-all", "--score-only"]])
-def test_cli_batch_gpus_n_matches_one_gpu(built, tmp_path, flags):
+def test_cli_batch_gpus_n_matches_one_gpu(built, tmp_path, flags, fake_rccl):
     """`--gpus N`: one process per GPU, rank 0's options broadcast, contiguous shares of the pairs, results gathered and
     printed by rank 0.  The test box has one card, so N = 2 and N = 3 are rehearsed with the ranks sharing it and the
-    collectives going through the rendezvous directory (AT_COMM=files -- RCCL refuses two ranks on one device); N = 1
+    collectives going through a stand-in for librccl.so (AT_RCCL_LIB = tests/c/fake_rccl_files.c, files in the rendezvous
+    directory: RCCL itself refuses two ranks on one device -- the product library holds no such transport); N = 1
     needs no collective.  Output and return code must equal the single-process run byte for byte."""
     _reads_file(tmp_path / "reads.fa", 14, 5)
     base = [EXE, "batch", "local", "-m", "2", "-u", "-2", "-o", "-5", "-e", "-2"] + flags
     one = subprocess.run(base + ["reads.fa"], cwd=tmp_path, capture_output=True)
     assert one.returncode == 0, one.stderr
-    env = dict(os.environ, AT_COMM="files", AT_ONE_DEVICE="1")
+    env = dict(os.environ, AT_RCCL_LIB=fake_rccl, AT_ONE_DEVICE="1")
     for n in (1, 2, 3):
         p = subprocess.run(base + ["--gpus", str(n), "reads.fa"], cwd=tmp_path, capture_output=True, env=env, timeout=600)
         assert p.returncode == 0, (n, p.stderr[-2000:])
@@ -296,3 +297,36 @@ def test_cli_input_files_match_reference(built, tmp_path, case):
     """Multi-line / CRLF / FASTQ / gzip / lower-case / commented inputs through every sub-command: stdout, stderr and
     return code equal what the stock binary printed on the same files."""
     _replay(case, tmp_path)
+
+
+@pytest.mark.gpu
+def test_cli_batch_all_vs_all_min_score(built, tmp_path, fake_rccl):
+    """`batch overlap --all-vs-all --score-only --min-score T` prints the lines of the unthresholded run whose score reaches T, in the
+    same order (pairs the bit-parallel bound proves below T are not swept at all); with --gpus N too; and the flag goes with
+    overlap --all-vs-all --score-only only."""
+    rng = random.Random(23)
+    n = 400
+    reads = ["".join(rng.choice("ACGT") for _ in range(rng.randint(300, 400))) for _ in range(n)]
+    for k in range(0, n - 1, 5):       # real overlaps: read k + 1 starts with the end of read k
+        ov = rng.randint(40, 250)
+        reads[k + 1] = (reads[k][-ov:] + reads[k + 1])[:400]
+    with open(tmp_path / "reads.fa", "w") as fh:
+        for k, r in enumerate(reads):
+            fh.write(">r%d\n%s\n" % (k, r))
+    base = [EXE, "batch", "overlap", "--all-vs-all", "--score-only"]
+    full = subprocess.run(base + ["reads.fa"], cwd=tmp_path, capture_output=True, timeout=600)
+    assert full.returncode == 0, full.stderr[-2000:]
+    lines = full.stdout.decode().splitlines()
+    assert len(lines) == n * (n - 1) // 2
+    for T in (25, 100):
+        want = [ln for ln in lines if float(ln.rsplit("score=", 1)[1]) >= T]
+        assert len(want) >= (40 if T == 25 else 20)
+        p = subprocess.run(base + ["--min-score", str(T), "reads.fa"], cwd=tmp_path, capture_output=True, timeout=600)
+        assert p.returncode == 0, p.stderr[-2000:]
+        assert p.stdout.decode().splitlines() == want, T
+        env = dict(os.environ, AT_RCCL_LIB=fake_rccl, AT_ONE_DEVICE="1")
+        p = subprocess.run(base + ["--min-score", str(T), "--gpus", "2", "reads.fa"], cwd=tmp_path, capture_output=True, timeout=600, env=env)
+        assert p.returncode == 0, p.stderr[-2000:]
+        assert p.stdout.decode().splitlines() == want, T
+    p = subprocess.run([EXE, "batch", "local", "--all-vs-all", "--score-only", "--min-score", "5", "reads.fa"], cwd=tmp_path, capture_output=True)
+    assert p.returncode == 1 and b"--min-score goes with" in p.stderr

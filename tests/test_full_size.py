@@ -106,6 +106,13 @@ def test_c5_all_vs_all_fifty_thousand_reads_streamed():
     from aligntools.c_amd.synth import synth_pairs_blob
     nreads, L = 50_000, 1000
     blob = synth_pairs_blob(0x5EED0005, nreads // 2, L, L).reshape(-1).copy()      # 25 000 rows of two reads
+    # a few real overlaps among the unrelated reads: read 2k + 1 starts with the last 100 .. 800 bases of read 2k, every 40th base changed
+    prng = random.Random(77)
+    for k in list(range(0, 400, 2)) + list(range(nreads - 400, nreads, 2)) + [prng.randrange(nreads // 2) * 2 for _ in range(300)]:
+        ov = prng.randint(100, 800)
+        piece = blob[(k + 1) * L - ov:(k + 1) * L].copy()
+        piece[::40] = ord("A")
+        blob[(k + 1) * L:(k + 1) * L + ov] = piece
     off = np.arange(nreads, dtype=np.int64) * L
     lens = np.full(nreads, L, dtype=np.int32)
     total = nreads * (nreads - 1) // 2
@@ -157,3 +164,43 @@ def test_c5_all_vs_all_fifty_thousand_reads_streamed():
             b = p - a * (2 * nreads - a - 1) // 2 + a + 1
             ref = O.align(O.OVERLAP, blob[a * L:(a + 1) * L].tobytes(), blob[b * L:(b + 1) * L].tobytes(), 1, -2, -5, -1)
             assert (int(kept[w][0, q]), int(kept[w][1, q]), int(kept[w][2, q])) == (ref["score"], ref["end_i"], ref["end_j"]), (p, a, b)
+
+    # ---- the same triangle with a threshold (at_set_min_score, the bit-parallel overlap filter of at_myers.hip.h): pairs proven below
+    # T are not swept.  The whole triangle in well under a minute; in the three windows every pair the filter let through carries the
+    # exact results of the run above, every pair it stopped scores below T there, and nothing that reaches T was stopped.
+    import time
+    T = 30
+    kept2 = [np.zeros((2, W), dtype=np.int32) for _ in windows]
+    st2 = {"next": 0, "swept": 0, "hits": 0}
+
+    def on3(first, sc, ei, ej, st):
+        assert first == st2["next"]
+        n = len(sc)
+        st2["next"] = first + n
+        st2["swept"] += int((st == 2).sum())
+        st2["hits"] += int(((st == 2) & (sc >= T)).sum())
+        assert (((st == 0) & (sc < T)) | (st == 2)).all()
+        for w, lo in enumerate(windows):
+            a, b = max(first, lo), min(first + n, lo + W)
+            if a < b:
+                kept2[w][0, a - lo:b - lo] = sc[a - first:b - first]
+                kept2[w][1, a - lo:b - lo] = st[a - first:b - first]
+    al.set_min_score(T)
+    t0 = time.time()
+    al.align_allpairs_stream("overlap", blob, off, lens, 0, total, chunk, on3)
+    dt = time.time() - t0
+    al.set_min_score(None)
+    assert "overlap filter" in al.last_config, al.last_config
+    assert st2["next"] == total
+    assert dt < 60.0, dt                                   # (the unthresholded triangle takes 110 s)
+    assert st2["swept"] < total // 100, st2["swept"]       # unrelated reads are stopped by the bound
+    nhit = 0
+    for w in range(len(windows)):
+        swept = kept2[w][1] == 2
+        assert (kept2[w][0][swept] == kept[w][0][swept]).all(), w
+        assert (kept[w][0][~swept] < T).all(), w
+        assert (kept2[w][0][~swept] >= kept[w][0][~swept]).all(), w
+        nhit += int((kept[w][0] >= T).sum())
+    assert nhit >= 300 and st2["hits"] >= nhit              # the planted overlaps of the first and last reads are found
+    print("C5 triangle with --min-score %d: %.1f s, %d of %d pairs swept, %d score >= T" % (T, dt, st2["swept"], total, st2["hits"]))
+    al.close()

@@ -479,9 +479,9 @@ def test_baseline_shapes_at_scale(al, cfg):
     half of the pairs unrelated, half related (long tracebacks with gaps)."""
     from aligntools.c_amd.synth import synth_pairs_blob, mutate_pairs
     mode, l1, l2, n, sc, uj, sites, nsample = {
-        "C3": ("global", 1024, 1024, 10000, (1, -1, -4, -1, -10), False, [], 12),      # the config's own 10 000 pairs
+        "C3": ("global", 1024, 1024, 10000, (1, -1, -4, -1, -10), False, [], 200),     # the config's own 10 000 pairs
         "C4": ("fit", 150, 500, 40000, (2, -2, -5, -1, -10), True, [100, 200, 300, 400], 150),
-        "C5": ("overlap", 1000, 1000, 3000, (1, -2, -5, -1, -10), False, [], 12),
+        "C5": ("overlap", 1000, 1000, 3000, (1, -2, -5, -1, -10), False, [], 200),
     }[cfg]
     blob = synth_pairs_blob(0x5EED0100 + len(cfg) + ord(cfg[1]), n, l1, l2)
     rel = mutate_pairs(blob, l1, l2, 7, sub=0.06)
@@ -510,6 +510,16 @@ def test_baseline_shapes_at_scale(al, cfg):
         got, i0, j0 = _rescore_np(res["ops"][k], pairs[k][0], pairs[k][1], ei, ej, m_, u_, o_, e_, g_, mode)
         assert got == int(res["score"][k]), (cfg, k, got, int(res["score"][k]))
         assert (i0, j0) == (0, 0) if mode == "global" else (i0 == 0 if mode == "fit" else j0 == 0), (cfg, k, i0, j0)
+    # the same batch under a tie-heavy scoring (1 / -1 / -1 / -1: most cells have several equal candidates), where a wrong first-wins
+    # order gives another path of the SAME score -- invisible to the re-scoring above, visible to the oracle
+    tie = (1, -1, -1, -1, -2)
+    al.set_scoring(*tie, uj, sites)
+    res = al.align_batch(mode, pairs, render=False)
+    assert (res["nops"] >= 0).all()
+    for k in rng.sample(range(n), max(nsample, 200)):
+        r = O.align(O.MODE_NAMES[mode], pairs[k][0], pairs[k][1], *tie, uj, sites)
+        assert (int(res["score"][k]), int(res["end_i"][k]), int(res["end_j"][k]), int(res["state"][k]), res["ops"][k]) == \
+               (r["score"], r["end_i"], r["end_j"], r["state"], r["ops"]), (cfg, "tie-heavy", k)
 
 
 def test_device_entry_refuses_broken_uniform_promise(al):

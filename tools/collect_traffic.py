@@ -64,8 +64,8 @@ def per_kernel(rows):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("workloads", nargs="+")
-    ap.add_argument("--out", default=os.path.join(ROOT, "gpurun_out", "r03", "pmc"))
-    ap.add_argument("--round", type=int, default=3)
+    ap.add_argument("--out", default=os.path.join(ROOT, "gpurun_out", "r04", "pmc"))
+    ap.add_argument("--round", type=int, default=4)
     ap.add_argument("--no-traceback", action="store_true")
     args = ap.parse_args()
     args.out = os.path.abspath(args.out)   # rocprofv3 runs with cwd=/tmp

@@ -476,8 +476,8 @@ static Layout16 layout16_for(bool tb, bool hasj, int l1, int l2, int ts, int for
 	nref = (nref + 1) & ~1LL;
 	/* (two-pass tracebacks: the boundary row's words double as the replay's staging area and the walkers' tile cache) */
 	/* (... the replay's rows above, CK + 1 entries of two words per lane; then every walker's copy of the block it walks) */
-	const long long walk_words = ((L.k + 3) / 4 + (hasj ? ((L.k + 3) / 4 + 3) / 4 : 0)) * (long long)AT_CK_STEPS;
-	const long long nbound = std::max<long long>(2LL * (l2 + 2), two_pass ? std::max<long long>(at::ck_stage_words(AT_CK_STEPS), 2 * ng * walk_words * (L.g == 64 ? 4 : 1)) : 0);
+	const long long walk_words = ((L.k + 3) / 4 + (hasj ? ((L.k + 3) / 4 + 3) / 4 : 0)) * (long long)at::ck_steps(L.g);
+	const long long nbound = std::max<long long>(2LL * (l2 + 2), two_pass ? std::max<long long>(at::ck_stage_words(at::ck_steps(L.g)), 2 * ng * walk_words * (L.g == 64 ? 4 : 1)) : 0);
 	/* steps per pointer word (and alignment): 4-bit cells, 4; the jump state with scores x4 keeps byte cells, 2 -- with scores x16 it has
 	 * 4-bit cells plus a bit plane of one word per 4 rows x 4 steps behind the cells (at_sweep16.hip.h: JPL); packed overlap: 2-bit cells, 8 */
 	const int spw = overlap ? 16 / AT_OVL_BITS : (hasj && !(ts == 4 && AT_JPLANE)) ? 2 : 4;
@@ -539,7 +539,7 @@ struct TpLayout {
 };
 static TpLayout tp_layout(const Layout16 &L, int kmode, int l2)
 {
-	const int blk = L.g <= 16 ? 4 : 8, cb = AT_CK_STEPS;
+	const int blk = L.g <= 16 ? 4 : 8, cb = at::ck_steps(L.g);
 	const long long T = (long long)((l2 + L.g - 1 + blk - 1) / blk) * blk;   /* steps of a sweep */
 	const int es = kmode == at::K_FITJ ? 4 : 3, nq = ((kmode == at::K_FITJ ? 3 : 2) * L.k + 3) / 4, kg = (L.k + 3) / 4;
 	auto up4 = [](long long v) { return (v + 3) & ~3LL; };
@@ -927,7 +927,7 @@ static int align_device(at_handle *h, int mode, int64_t npairs,
 		char tag16[112];
 		snprintf(tag16, sizeof tag16, "packed16 x%d bits=%d %dx%d-lane groups (%d pairs/wave)%s", 1 << ts, bits, 64 / P.g, P.g, per_wave,
 		         rag ? " ragged frames" : "");
-		if (two_pass) snprintf(tag16 + strlen(tag16), sizeof tag16 - strlen(tag16), " two-pass ck=%d", AT_CK_STEPS);
+		if (two_pass) snprintf(tag16 + strlen(tag16), sizeof tag16 - strlen(tag16), " two-pass ck=%d", at::ck_steps(P.g));
 		auto pick = [&](int st) {
 			if (two_pass) return st == 1 ? at_pick16_tp(kmode, P.g, P.k, ts, bits) : (at_sweep16_fn) nullptr;
 			return rag ? at_pick16_rag(kmode, P.g, P.k, st, tb, bits) : at_pick16(kmode, P.g, P.k, ts, st, tb, bits);

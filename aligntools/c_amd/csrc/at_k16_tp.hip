@@ -5,7 +5,7 @@ template <int MODE>
 static at_sweep16_fn tp8(int k)
 {
 	switch (k) {
-	case 19: return at::at_sweep16<MODE, 8, 19, 4, true, false, false, false, AT_BITS16, AT_CK_STEPS>;
+	case 19: return at::at_sweep16<MODE, 8, 19, 4, true, false, false, false, AT_BITS16, at::ck_steps(8)>;
 	default: return nullptr;
 	}
 }

@@ -5,7 +5,7 @@ template <int MODE, int TS>
 static at_sweep16_fn tp64(int k)
 {
 	switch (k) {
-	case 16: return at::at_sweep16<MODE, 64, 16, TS, true, false, false, false, AT_BITS16, AT_CK_STEPS>;
+	case 16: return at::at_sweep16<MODE, 64, 16, TS, true, false, false, false, AT_BITS16, at::ck_steps(64)>;
 	default: return nullptr;
 	}
 }

@@ -231,16 +231,38 @@ AT_DEV int pidx(int wr, int r, int lane, int NL)
  * cells), its pointer words go to a small region of the slot, and the alignment's walker consumes them until it leaves
  * the blocks of the round.  Pointers depend on nothing but the exact boundary values, so the ops are those of the
  * one-pass kernels (trace_back_gla / _local_affine / _fit_affine_jump, alignment.h:372-412, 558-592, 766-800).
+ *
+ * A round, in order: (1) every walker's anchor goes to the lanes of its group (shuffles), each lane works out its two
+ * blocks; (2) replay16_block: the CB + 1 row-checkpoint entries above the block are loaded together and staged in LDS as
+ * the lane below sees them (tagged X', L of the row below), the state at the block's first step is rebuilt from the column
+ * checkpoint (or the border), CB steps are swept, the pointer words stored; (3) the walks, in PHASES: every walker names
+ * the block it stands in, the wave copies those blocks from the slot into LDS together (one round trip), every walker
+ * walks its block -- four cells ahead along its direction per look, the state machine in bit arithmetic -- until it
+ * leaves what it holds; a walker that stands in a block the round has not replayed waits for the next round.
+ *
+ * What it buys (one MI355X, profiles/r04/two_pass_ab.jsonl): the 64-lane group with 16 rows per lane -- reads of 609 .. 1 024
+ * bases, where the one-pass kernels hold 4 rows per lane in four strips -- C3 2 940 -> 3 170 GCUPS with launches in flight,
+ * 2 110 -> 2 860 one launch at a time: the default there.  The 8-lane groups x 19 rows lose (C2 3 050 -> 2 850, C4 2 200 ->
+ * 1 580: a round replays 19 x 16 cells in every lane for the dozen cells a short walk needs, and long walks need ten rounds)
+ * and stay on the one-pass kernels unless AT_TWO_PASS=2 asks.
  * ====================================================================================================================== */
 #ifndef AT_TP_STATS
 #define AT_TP_STATS 0     /* 1: throw-away build that counts rounds / items / walk ops / cycles in the words behind the work counter */
 #endif
 #ifndef AT_TP_ONEBODY
-#define AT_TP_ONEBODY 1
+#define AT_TP_ONEBODY 1   /* the forward sweep of a CK kernel keeps one (masked) step body: 45 KB of code instead of 58 on the 64-lane group */
 #endif
 #ifndef AT_CK_STEPS
-#define AT_CK_STEPS 16    /* CB: steps between two column checkpoints = columns of a replayed block */
+#define AT_CK_STEPS 16    /* CB: steps between two column checkpoints = columns of a replayed block (groups of up to 32 lanes) */
 #endif
+#ifndef AT_CK_STEPS64
+#define AT_CK_STEPS64 32  /* ... on the 64-lane group (its LDS holds a staging area of 33 steps): half the column checkpoints of the forward
+                           * sweep, half the block visits of a walk, 4.3 rounds per C3 alignment instead of 7.1 -- C3 2 987 -> 3 159 GCUPS */
+#endif
+#ifndef AT_CK_W64
+#define AT_CK_W64 3       /* t-blocks per band of a round on the 64-lane group */
+#endif
+constexpr int ck_steps(int g) { return g == 64 ? AT_CK_STEPS64 : AT_CK_STEPS; }
 template <int MODE> constexpr int ck_es() { return MODE == K_FITJ ? 4 : 3; }                     /* words of a row checkpoint entry */
 template <int MODE, int K> constexpr int ck_nq() { return ((MODE == K_FITJ ? 3 : 2) * K + 3) / 4; }   /* 16-byte chunks of a column checkpoint */
 constexpr int ck_log2(int v) { return v <= 1 ? 0 : 1 + ck_log2(v / 2); }
@@ -257,7 +279,7 @@ struct CkPattern {
 	 * blocks up a hundred times).  Narrower groups have 4 .. 32 slots and spend them exactly: band by band the t-blocks the ray
 	 * crosses, MU / ML steps of margin above / below it (an L op moves a walk above the ray, a U op below). */
 	static constexpr bool FIXED = G == 64;
-	static constexpr int W = 3, NB = G / W;
+	static constexpr int W = AT_CK_W64, NB = G / W;
 	static constexpr int MHr = (W * CB - K) / 2, MH = MHr < 0 ? 0 : MHr > CB ? CB : MHr;
 	static constexpr int MU = 3, ML = 3;
 	int b, c0, thi1, horiz;
@@ -346,7 +368,7 @@ struct ck_u3 { uint32_t x, y, z; };
  * and runs CB steps; the cell of step t sits at s = t - org.  Steps behind column l2 and rows behind l1 compute cells
  * nobody reads, as in the forward sweep. */
 #ifndef AT_REPLAY_INLINE
-#define AT_REPLAY_INLINE 1    /* 0: the replay as a function call (A/B: C2 1 943 against 2 120 GCUPS inlined, on the first version) */
+#define AT_REPLAY_INLINE 1    /* 0: the replay as a function call (A/B on the first version: C2 1 943 against 2 120 GCUPS inlined) */
 #endif
 #if AT_REPLAY_INLINE
 #define AT_REPLAY_FN AT_DEV

@@ -1115,6 +1115,49 @@ static int align_device(at_handle *h, int mode, int64_t npairs,
 	return AT_OK;
 }
 
+/* ---- host entry: 2-bit packing while staging (round 4) ----
+ * The host entry used to copy every raw byte into page-locked memory and send it up (30 MB per 100k pairs of C2), the GPU packed.
+ * The staging pass already touches every byte: it now packs them -- 16 bases per word, the layout of at_pack<2> -- so a quarter of
+ * the bytes cross the link, and the sweeps, which wait for their chunk's upload, start that much earlier.  32 bases per step:
+ * code = ((c >> 1) ^ (c >> 2)) & 3 maps A C G T to 0 1 2 3, a byte shuffle of "ACGT" by the code must give the byte back (else the
+ * batch is not pure ACGT: the raw path takes over, as before), two multiply-adds fold four codes into a byte. */
+#if defined(__x86_64__)
+#include <immintrin.h>
+__attribute__((target("avx2"))) static inline __m256i pack2_step(__m256i v, __m256i bad, uint32_t *dst)
+{
+	const __m256i m3 = _mm256_set1_epi8(3), w14 = _mm256_set1_epi16(0x0401), w116 = _mm256_set1_epi32(0x00100001);
+	const __m256i acgt = _mm256_setr_epi8('A', 'C', 'G', 'T', 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 'A', 'C', 'G', 'T', 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0);
+	const __m256i pickb = _mm256_setr_epi8(0, 4, 8, 12, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, 0, 4, 8, 12, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1);
+	const __m256i code = _mm256_and_si256(_mm256_xor_si256(_mm256_srli_epi16(v, 1), _mm256_srli_epi16(v, 2)), m3);
+	const __m256i x = _mm256_madd_epi16(_mm256_maddubs_epi16(code, w14), w116);   /* a byte per 4 bases in every dword */
+	const __m256i y = _mm256_shuffle_epi8(x, pickb);
+	const uint64_t r = (uint64_t)(uint32_t)_mm256_extract_epi32(y, 0) | ((uint64_t)(uint32_t)_mm256_extract_epi32(y, 4) << 32);
+	memcpy(dst, &r, 8);
+	return _mm256_or_si256(bad, _mm256_xor_si256(_mm256_shuffle_epi8(acgt, code), v));
+}
+/* `len` bytes of ACGT -> (len + 15) / 16 + 1 words (the last one the padding word the kernels' windows read ahead into); false if a
+ * byte is not one of ACGT (the words are then unspecified) */
+__attribute__((target("avx2"))) static bool pack2_avx2(const uint8_t *src, int len, uint32_t *dst)
+{
+	const int nw = (len + 15) / 16 + 1;
+	__m256i bad = _mm256_setzero_si256();
+	int b = 0;
+	for (; b + 32 <= len; b += 32) bad = pack2_step(_mm256_loadu_si256((const __m256i *)(src + b)), bad, dst + b / 16);
+	if (b < len) {   /* (the last 1 .. 31 bases, filled up with A = code 0: its two words end at or before the padding word) */
+		alignas(32) uint8_t tail[32];
+		memset(tail, 'A', 32);
+		memcpy(tail, src + b, (size_t)(len - b));
+		bad = pack2_step(_mm256_load_si256((const __m256i *)tail), bad, dst + b / 16);
+	}
+	dst[nw - 1] = 0;
+	return _mm256_testz_si256(bad, bad) != 0;
+}
+static bool host_pack_available() { static const bool ok = __builtin_cpu_supports("avx2"); return ok; }
+#else
+static bool pack2_avx2(const uint8_t *, int, uint32_t *) { return false; }
+static bool host_pack_available() { return false; }
+#endif
+
 /* AT_HOST_TRACE=1: microseconds since the first call at the stages of the host entry, on stderr (where does a call's time go?) */
 static void htrace(const char *what, long long a)
 {
@@ -1234,7 +1277,31 @@ static int align_host(at_handle *h, int mode, int64_t npairs, const uint8_t *seq
 	 * 1.90-2.12 ms against 1.99-2.04 with tracebacks, and 1.65-1.77 against 1.21-1.37 scores only -- copies queued side by side on six
 	 * streams move more bytes per second than the same copies one behind the other.) */
 	HIP_TRY(h, hipMemcpyAsync(dd, hd, up_bytes, hipMemcpyHostToDevice, s));
-	if (caller_pinned) HIP_TRY(h, hipMemcpyAsync(d_blob, up_src, (size_t)blob_bytes, hipMemcpyHostToDevice, s));
+	/* pure-ACGT batches are packed HERE, while they are staged: the words go up (a quarter of the bytes), the raw blob and the GPU's
+	 * packing kernel are skipped.  The first byte that is not ACGT ends the attempt: the raw path below takes the whole chunk. */
+	bool host_packed = false;
+	if (!force8 && !caller_pinned && host_pack_available() && env_ll("AT_HOST_PACK", 1)) {
+		rc = grow_pinned(h, &h->hp_blob, &h->hp_blob_bytes, (size_t)(nwords2 + 4) * 4 + 64);
+		if (rc) return rc;
+		uint32_t *hw = (uint32_t *)h->hp_blob;
+		const int64_t piece_words = std::max<long long>(4096, env_ll("AT_HOST_STAGE_PIECE", 4 << 20)) / 16;   /* (a quarter of the raw pieces' bytes) */
+		int64_t sent = 0;
+		bool ok = true;
+		for (int64_t k = 0; k < 2 * npairs && ok; ++k) {
+			ok = pack2_avx2(up_src + p_soff[k], p_slen[k], hw + p_sw[k]);
+			const int64_t done = k + 1 < 2 * npairs ? p_sw[k + 1] : nwords2;
+			if (ok && (done - sent >= piece_words || k + 1 == 2 * npairs)) {
+				if (k + 1 == 2 * npairs) for (int x = 0; x < 4; ++x) hw[nwords2 + x] = 0;
+				const int64_t upto = k + 1 == 2 * npairs ? nwords2 + 4 : done;
+				HIP_TRY(h, hipMemcpyAsync(d_words + sent, hw + sent, (size_t)(upto - sent) * 4, hipMemcpyHostToDevice, s));
+				sent = upto;
+			}
+		}
+		host_packed = ok;
+		if (!ok) HIP_TRY(h, hipStreamSynchronize(s));     /* (hp_blob is about to be reused for the raw bytes) */
+	}
+	if (host_packed) {
+	} else if (caller_pinned) HIP_TRY(h, hipMemcpyAsync(d_blob, up_src, (size_t)blob_bytes, hipMemcpyHostToDevice, s));
 	else {
 		/* pieces of 4 MB: the staging of one beside the transfer of the one before (copies of 1 MB cross the link at 32 GB/s,
 		 * of 5 MB at 50: tools/pcie_rate.py) */
@@ -1252,7 +1319,7 @@ static int align_host(at_handle *h, int mode, int64_t npairs, const uint8_t *seq
 	int bits = force8 ? 8 : 2;
 	int *p_flag = (int *)((char *)h->hp_flag);
 	bool flag_pending = false;
-	if (bits == 2) {
+	if (bits == 2 && !host_packed) {
 		HIP_TRY(h, hipMemsetAsync(d_flag, 0, 4, s));
 		hipLaunchKernelGGL(at::at_pack<2>, dim3(pgrid), dim3(256), 0, s, pa);
 		HIP_TRY(h, hipMemcpyAsync(p_flag, d_flag, 4, hipMemcpyDeviceToHost, s));

@@ -89,6 +89,7 @@ struct at_handle {
 	/* device scratch (grow-only) */
 	uint32_t *d_sitemask = nullptr; size_t sitemask_words = 0; int sitemask_for_l2 = -1; bool sitemask_dirty = true;
 	uint32_t *d_ws = nullptr; size_t ws_bytes = 0;
+	uint32_t *d_ck = nullptr; size_t ck_bytes = 0;   /* two-pass tracebacks with a walk kernel: a launch's checkpoints */
 	unsigned long long *d_queue = nullptr;
 	int last_span = 0;              /* max_len1 + max_len2 of the handle's latest batch: the rendering kernel's hint for its group width */
 	void *d_in = nullptr; size_t in_bytes = 0;
@@ -215,6 +216,7 @@ extern "C" void at_destroy(at_handle *h)
 	(void)hipSetDevice(h->device);
 	if (h->d_sitemask) (void)hipFree(h->d_sitemask);
 	if (h->d_ws) (void)hipFree(h->d_ws);
+	if (h->d_ck) (void)hipFree(h->d_ck);
 	if (h->d_queue) (void)hipFree(h->d_queue);
 	if (h->d_in) (void)hipFree(h->d_in);
 	if (h->d_out) (void)hipFree(h->d_out);
@@ -422,7 +424,7 @@ struct Layout16 {
  * lanes (8 alignments per wave, 85 %; one group of 64 lanes: 59 %) and so do 209..304 bases with 16 / 19 rows per lane,
  * 305..608 bases as 2 groups of 32 lanes (10 .. 19 rows per lane), everything
  * else as one group of 64 lanes.  AT_GROUP = 8 / 16 / 32 / 64 caps the choice (A/B runs); ragged frames name their group width themselves. */
-static Layout16 layout16_for(bool tb, bool hasj, int l1, int l2, int ts, int force_g = 0, bool overlap = false, int kmode = -1, int force_k = 0, bool two_pass = false)   /* force_g: 8 / 16 = ragged frames on that group width; 64 = the 64-lane items behind a batch of narrow-group items, force_k rows per lane */
+static Layout16 layout16_for(bool tb, bool hasj, int l1, int l2, int ts, int force_g = 0, bool overlap = false, int kmode = -1, int force_k = 0, int two_pass = 0)   /* two_pass: 1 = the rounds inside the sweep's kernel (its staging area and walkers' tiles in LDS), 2 = a walk kernel; force_g: 8 / 16 = ragged frames on that group width; 64 = the 64-lane items behind a batch of narrow-group items, force_k rows per lane */
 {
 	Layout16 L;
 	const long long g_forced = env_ll("AT_GROUP", 0);
@@ -477,7 +479,7 @@ static Layout16 layout16_for(bool tb, bool hasj, int l1, int l2, int ts, int for
 	/* (two-pass tracebacks: the boundary row's words double as the replay's staging area and the walkers' tile cache) */
 	/* (... the replay's rows above, CK + 1 entries of two words per lane; then every walker's copy of the block it walks) */
 	const long long walk_words = ((L.k + 3) / 4 + (hasj ? ((L.k + 3) / 4 + 3) / 4 : 0)) * (long long)at::ck_steps(L.g);
-	const long long nbound = std::max<long long>(2LL * (l2 + 2), two_pass ? std::max<long long>(at::ck_stage_words(at::ck_steps(L.g)), 2 * ng * walk_words * (L.g == 64 ? 4 : 1)) : 0);
+	const long long nbound = std::max<long long>(2LL * (l2 + 2), two_pass == 1 ? std::max<long long>(at::ck_stage_words(at::ck_steps(L.g)), 2 * ng * walk_words * (L.g == 64 ? 4 : 1)) : 0);
 	/* steps per pointer word (and alignment): 4-bit cells, 4; the jump state with scores x4 keeps byte cells, 2 -- with scores x16 it has
 	 * 4-bit cells plus a bit plane of one word per 4 rows x 4 steps behind the cells (at_sweep16.hip.h: JPL); packed overlap: 2-bit cells, 8 */
 	const int spw = overlap ? 16 / AT_OVL_BITS : (hasj && !(ts == 4 && AT_JPLANE)) ? 2 : 4;
@@ -536,8 +538,10 @@ static bool packed_ok(const at_handle *h, int mode, int bits, int l1, int l2, in
 struct TpLayout {
 	int off_brow, off_rck, off_cck, off_rptr, off_rjpl;
 	long long words;
+	long long brow_words;
 };
-static TpLayout tp_layout(const Layout16 &L, int kmode, int l2)
+/* split: pass 2 is a kernel of its own -- the regions of a work item (row and column checkpoints); the border row is the launch's */
+static TpLayout tp_layout(const Layout16 &L, int kmode, int l2, bool split = false)
 {
 	const int blk = L.g <= 16 ? 4 : 8, cb = at::ck_steps(L.g);
 	const long long T = (long long)((l2 + L.g - 1 + blk - 1) / blk) * blk;   /* steps of a sweep */
@@ -545,12 +549,13 @@ static TpLayout tp_layout(const Layout16 &L, int kmode, int l2)
 	auto up4 = [](long long v) { return (v + 3) & ~3LL; };
 	TpLayout t;
 	long long w = 0;
-	t.off_brow = (int)w; w = up4(w + (T + cb + 2) * es);
-	t.off_rck = (int)w; w = up4(w + (T + cb + 2) * 64 * es);
-	t.off_cck = (int)w; w = up4(w + (T / cb + 3) * nq * 256);
-	t.off_rptr = (int)w; w = up4(w + (cb / 4) * ((L.k + 3) / 4) * 256);   /* [4 steps][4 rows][lane][row in group] */
-	t.off_rjpl = (int)w; w = up4(w + (cb / 4) * ((kg + 3) / 4) * 256);
-	t.words = w;
+	t.brow_words = (T + cb + 2) * es;
+	t.off_brow = (int)w; if (!split) w = up4(w + (T + cb + 2) * es);
+	t.off_rck = (int)w; w = up4(w + 64 * es + (T / cb + 3) * 64 * cb * es);   /* (ck_rck_word: the border entries, then tiles of steps) */
+	t.off_cck = (int)w; w = up4(w + (T / cb + 3) * ((nq + 3) / 4 * 4) * 256);   /* (ck_cck_word: chunks in groups of up to 4) */
+	t.off_rptr = (int)w; if (!split) w = up4(w + (cb / 4) * ((L.k + 3) / 4) * 256);   /* [4 steps][4 rows][lane][row in group] */
+	t.off_rjpl = (int)w; if (!split) w = up4(w + (cb / 4) * ((kg + 3) / 4) * 256);
+	t.words = split ? (w + 63) & ~63LL : w;
 	return t;
 }
 
@@ -685,7 +690,7 @@ static int plan_launch(at_handle *h, const char *tag, int k, long long nwork, lo
 		pl->ws = h->d_ws;
 	}
 	pl->grid = grid;
-	if (!h->d_queue) { HIP_TRY(h, hipMalloc((void **)&h->d_queue, 64)); HIP_TRY(h, hipMemset(h->d_queue, 0, 64)); }
+	if (!h->d_queue) { HIP_TRY(h, hipMalloc((void **)&h->d_queue, 128)); HIP_TRY(h, hipMemset(h->d_queue, 0, 128)); }
 	HIP_TRY(h, hipMemsetAsync(h->d_queue, 0, 8, stream));
 	static const char *names[3] = {"lds", "lds+hbm-pointers", "hbm"};
 	snprintf(h->cfg, sizeof h->cfg, "%s store=%s rows/lane=%d lds=%zuB slot=%lldB waves/cu<=%lld grid=%lld", tag, names[store], k,
@@ -893,22 +898,49 @@ static int align_device(at_handle *h, int mode, int64_t npairs,
 	 * By default where that wins -- the 64-lane groups with 16 rows per lane (reads of 609 .. 1 024 bases: the one-pass kernels hold 4 rows
 	 * per lane there and need four strips); AT_TWO_PASS=2: wherever a CK kernel exists (the 8-lane groups x 19 rows lose: C2 -7 %, C4
 	 * -28 %, profiles/r04/two_pass_ab.txt), AT_TWO_PASS=0: never (A/B runs) */
-	bool two_pass = false;
+	bool two_pass = false, tp_split = false;
 	const long long tp_mode = env_ll("AT_TWO_PASS", 1);
 	if (ts && tb && !rag && kmode <= at::K_FITJ && tp_mode) {
-		const Layout16 P2 = layout16_for(false, kmode == at::K_FITJ, max_len1, max_len2, ts, 0, false, kmode, 0, true);
-		if ((P2.g == 64 || tp_mode == 2) && (long long)P2.g * P2.k >= max_len1 && at_pick16_tp(kmode, P2.g, P2.k, ts, bits) &&
+		Layout16 P2 = layout16_for(false, kmode == at::K_FITJ, max_len1, max_len2, ts, 0, false, kmode, 0, 1);
+		if ((P2.g == 64 || tp_mode >= 2) && (long long)P2.g * P2.k >= max_len1 && at_pick16_tp(kmode, P2.g, P2.k, ts, bits) &&
 		    choose_store(P2.off_ptr, 1, true) == 1) {
 			two_pass = true;
+			/* pass 2 as a kernel of its own (at_walk16.hip.h): the sweep leaves its checkpoints per work item, one walker per half-lane
+			 * replays the blocks its walk crosses.  AT_TP_SPLIT=0: the rounds inside the sweep's kernel (A/B runs) */
+			tp_split = env_ll("AT_TP_SPLIT", 1) && at_pick_walk16(kmode, P2.g, P2.k, ts, bits) != nullptr;
+			if (tp_split) P2 = layout16_for(false, kmode == at::K_FITJ, max_len1, max_len2, ts, 0, false, kmode, 0, 2);
 			P = P2;
 		}
 	}
 	if (ts) {
+		const int per_wave = 2 * (64 / P.g);
+		/* the sliver's layout (see below) */
+		const bool tail_ok = !rag && !only_if && P.g <= 16 && kmode != at::K_OVERLAP && env_ll("AT_TAIL_SPLIT", 1) &&
+		                     (!tp_split || P.g == 8);   /* (the walk kernels of the 8-lane groups carry their sliver's walks) */
+		Layout16 PT = P;
+		if (tail_ok) PT = layout16_for(tb && !two_pass, kmode == at::K_FITJ, max_len1, max_len2, ts, at::AT_TAIL_G, false, kmode, at::at_tail_k(P.g, P.k), two_pass ? (tp_split ? 2 : 1) : 0);
+		TpLayout tpm{}, tpt{};
+		if (two_pass) { tpm = tp_layout(P, kmode, max_len2, tp_split); tpt = tp_layout(PT, kmode, max_len2, tp_split); }
+		/* split two-pass: the checkpoints of a whole launch live side by side -- C2 225 KB, C3 / C4 1.1 MB per work item -- so a batch is
+		 * swept and walked in pieces whose checkpoints fit AT_CK_CAP_MB (8 192) */
+		int64_t piece = npairs;
+		int64_t brow_words = 0;
+		if (tp_split) {
+			const long long cap = env_ll("AT_CK_CAP_MB", 8192) << 20;
+			brow_words = (tpm.brow_words + 63) & ~63LL;
+			const long long tail_reserve = tail_ok ? 16LL * h->ncu * tpt.words * 4 : 0;
+			const long long items = (cap - tail_reserve - brow_words * 4) / (tpm.words * 4 + 16LL * per_wave);
+			if (items < 1) return fail(h, AT_ERR_NOMEM, "two-pass tracebacks: one work item's checkpoints (%lld bytes) exceed AT_CK_CAP_MB", tpm.words * 4);
+			piece = std::min<int64_t>(npairs, items * per_wave);
+		}
+		std::string cfg_first;
+		for (int64_t first = 0; first < npairs; first += piece) {
+		const int64_t np = std::min<int64_t>(piece, npairs - first);
 		Sweep16Args b;
 		memset(&b, 0, sizeof b);
-		b.npairs = npairs; b.seq = d_seq;
-		b.woff1 = (const long long *)d_woff1; b.woff2 = (const long long *)d_woff2;
-		b.len1 = d_len1; b.len2 = d_len2;
+		b.npairs = np; b.seq = d_seq;
+		b.woff1 = (const long long *)d_woff1 + first; b.woff2 = (const long long *)d_woff2 + first;
+		b.len1 = d_len1 + first; b.len2 = d_len2 + first;
 		b.l1 = max_len1; b.l2 = max_len2;
 		const int sc = 1 << ts;
 		b.m16 = h->m * sc; b.u16 = h->u * sc; b.o16 = h->o * sc; b.e16 = h->e * sc; b.g16 = h->j * sc; b.thresh16 = thresh16;
@@ -917,22 +949,22 @@ static int align_device(at_handle *h, int mode, int64_t npairs,
 			if (rcs) return rcs;
 			b.sitemask = h->d_sitemask;
 		}
-		b.score = d_score; b.end_i = d_end_i; b.end_j = d_end_j; b.state = d_state;
-		b.ops = d_ops; b.ops_off = (const long long *)d_ops_off; b.nops = d_nops;
+		b.score = d_score + first; b.end_i = d_end_i ? d_end_i + first : nullptr; b.end_j = d_end_j ? d_end_j + first : nullptr;
+		b.state = d_state ? d_state + first : nullptr;
+		b.ops = d_ops; b.ops_off = d_ops_off ? (const long long *)d_ops_off + first : nullptr; b.nops = d_nops ? d_nops + first : nullptr;
 		b.order = rag ? d_order : nullptr;
 		b.only_if = only_if; b.only_val = only_val;
 		b.off_refb = P.off_refb; b.off_bound = P.off_bound; b.ptr_lanes = P.ptr_lanes; b.off_sm = P.off_sm; b.nsm = P.nsm;
 		Plan pl;
-		const int per_wave = 2 * (64 / P.g);
-		char tag16[112];
+		char tag16[128];
 		snprintf(tag16, sizeof tag16, "packed16 x%d bits=%d %dx%d-lane groups (%d pairs/wave)%s", 1 << ts, bits, 64 / P.g, P.g, per_wave,
 		         rag ? " ragged frames" : "");
-		if (two_pass) snprintf(tag16 + strlen(tag16), sizeof tag16 - strlen(tag16), " two-pass ck=%d", at::ck_steps(P.g));
+		if (two_pass) snprintf(tag16 + strlen(tag16), sizeof tag16 - strlen(tag16), " two-pass%s ck=%d", tp_split ? " (walk kernel)" : "", at::ck_steps(P.g));
 		auto pick = [&](int st) {
-			if (two_pass) return st == 1 ? at_pick16_tp(kmode, P.g, P.k, ts, bits) : (at_sweep16_fn) nullptr;
+			if (two_pass) return st == 1 ? at_pick16_tp(kmode, P.g, P.k, ts, bits, tp_split) : (at_sweep16_fn) nullptr;
 			return rag ? at_pick16_rag(kmode, P.g, P.k, st, tb, bits) : at_pick16(kmode, P.g, P.k, ts, st, tb, bits);
 		};
-		const long long nwork = (npairs + per_wave - 1) / per_wave;
+		const long long nwork = (np + per_wave - 1) / per_wave;
 		/* The grid is the resident waves, each pulling work items until none are left.  A SIMD holds two of these waves and finishes
 		 * an item every ~118 us: C2's 6 250 items of 16 pairs on 1 024 SIMDs are 6.1 items per SIMD, so a launch that has the chip to
 		 * itself ends with 106 SIMDs working through a 7th item while the others idle (0.86 ms instead of 0.72).  When such a sliver
@@ -941,25 +973,26 @@ static int align_device(at_handle *h, int mode, int64_t npairs,
 		 * at_sweep16.hip.h).  AT_TAIL_SPLIT=0: off.  (Round 2 ran the sliver as a second launch behind the
 		 * main one, which cost a caller who keeps launches in flight 8 %; round 3 first tried it on a stream of its own beside the
 		 * main launch: +6.5 % alone, -8 % in flight -- the next batch's waves took the slots the sliver was waiting for.) */
-		const bool tail_ok = !rag && !only_if && P.g <= 16 && kmode != at::K_OVERLAP && env_ll("AT_TAIL_SPLIT", 1);
-		Layout16 PT = P;
-		if (tail_ok) PT = layout16_for(tb && !two_pass, kmode == at::K_FITJ, max_len1, max_len2, ts, at::AT_TAIL_G, false, kmode, at::at_tail_k(P.g, P.k), two_pass);
-		TpLayout tpm = {0, 0, 0, 0, 0, 0}, tpt = tpm;
-		if (two_pass) { tpm = tp_layout(P, kmode, max_len2); tpt = tp_layout(PT, kmode, max_len2); }
 		/* (the sliver's items use the main items' LDS window and pointer slot: both hold either layout -- the main items' are the larger) */
 		int rc = plan_launch(h, tag16, P.k, nwork, std::max(P.off_ptr, PT.off_ptr),
-		                     two_pass ? std::max(tpm.words, tpt.words) : std::max(P.words - P.off_ptr, PT.words - PT.off_ptr), &pl, stream,
+		                     tp_split ? 64 : two_pass ? std::max(tpm.words, tpt.words) : std::max(P.words - P.off_ptr, PT.words - PT.off_ptr), &pl, stream,
 		                     [&](int st) { return (const void *)pick(st); }, P.g < 64 || rag || two_pass);
 		if (rc) return rc;
+		if (tp_split) {
+			/* AT_TP_RESERVE=n: the sweep leaves n wave slots per CU to the walk kernels of the launches around it (its waves are
+			 * persistent: a walk kernel queued behind it otherwise waits for the whole sweep of the NEXT launch to drain) */
+			const long long rsv = env_ll("AT_TP_RESERVE", 0) * h->ncu;
+			if (rsv > 0 && pl.grid > rsv && nwork > pl.grid - rsv) pl.grid = std::max<long long>(h->ncu, pl.grid - rsv);
+		}
 		int64_t n_tail = 0;
 		if (tail_ok && nwork > pl.grid) {
 			const long long sliver = nwork % pl.grid;
-			if (sliver > 0 && sliver * 4 <= pl.grid) n_tail = npairs - (nwork - sliver) * per_wave;   /* (four 32-lane items per 8-lane item: one per SIMD at most) */
+			if (sliver > 0 && sliver * 4 <= pl.grid) n_tail = np - (nwork - sliver) * per_wave;   /* (four 32-lane items per 8-lane item: one per SIMD at most) */
 		}
 		Sweep16Args bt = b;
 		bt.npairs = 0;
+		const int64_t nm = np - n_tail;
 		if (n_tail > 0) {
-			const int64_t nm = npairs - n_tail;
 			b.npairs = nm;
 			bt.npairs = n_tail;
 			bt.woff1 += nm; bt.woff2 += nm; bt.len1 += nm; bt.len2 += nm;
@@ -978,14 +1011,47 @@ static int align_device(at_handle *h, int mode, int64_t npairs,
 			b.off_brow = tpm.off_brow; b.off_rck = tpm.off_rck; b.off_cck = tpm.off_cck; b.off_rptr = tpm.off_rptr; b.off_rjpl = tpm.off_rjpl;
 			bt.off_brow = tpt.off_brow; bt.off_rck = tpt.off_rck; bt.off_cck = tpt.off_cck; bt.off_rptr = tpt.off_rptr; bt.off_rjpl = tpt.off_rjpl;
 		}
+		if (tp_split) {
+			/* [row 0 | end cells of the np alignments | the main items' checkpoints | the sliver items'] */
+			const long long n_main_items = (nm + per_wave - 1) / per_wave, n_tail_items = (n_tail + 2 * (64 / at::AT_TAIL_G) - 1) / (2 * (64 / at::AT_TAIL_G));
+			const long long end_words = ((np * 4) + 63) & ~63LL;
+			const size_t need = (size_t)(brow_words + end_words + n_main_items * tpm.words + n_tail_items * tpt.words) * 4;
+			void *pc = h->d_ck; size_t have = h->ck_bytes;
+			rc = grow(h, &pc, &have, need);
+			h->d_ck = (uint32_t *)pc; h->ck_bytes = have;
+			if (rc) return rc;
+			b.ck_brow = h->d_ck; bt.ck_brow = h->d_ck;
+			b.tp_end = (int4 *)(h->d_ck + brow_words); bt.tp_end = b.tp_end + nm;
+			b.ck = h->d_ck + brow_words + end_words; b.ck_item_words = tpm.words;
+			bt.ck = b.ck + n_main_items * tpm.words; bt.ck_item_words = tpt.words;
+		}
 		at_sweep16_fn fn16 = pick(pl.store);
 		if (!fn16 || (P.g != 64 && pl.store == 2)) return fail(h, AT_ERR_RANGE, "no packed kernel for this shape (rows/lane=%d, store=%d)", P.k, pl.store);
 		if (pl.dyn_lds > 48 * 1024)
 			HIP_TRY(h, hipFuncSetAttribute((const void *)fn16, hipFuncAttributeMaxDynamicSharedMemorySize, (int)pl.dyn_lds));
 		hipLaunchKernelGGL(fn16, dim3((unsigned)pl.grid), dim3(64), pl.dyn_lds, stream, b, bt);
 		HIP_TRY(h, hipGetLastError());
+		if (tp_split && !env_ll("AT_DIAG_NO_WALK_KERNEL", 0)) {   /* (1: throw-away runs without pass 2 -- what does the sweep alone reach?  Every pair reports garbage ops) */
+			at_walk16_fn wf = at_pick_walk16(kmode, P.g, P.k, ts, bits);
+			if (!wf) return fail(h, AT_ERR_RANGE, "no walk kernel for %d-lane groups x %d rows", P.g, P.k);
+			auto lds_of = [&](const Layout16 &L) {
+				const int cb = at::ck_steps(L.g), nsm = kmode == at::K_FITJ ? L.nsm : 0;
+				return (size_t)((nsm + 1) / 2 * 2 + (cb + 1) * 128 + 64 * (L.k * (cb / 4) + (kmode == at::K_FITJ ? (L.k + 3) / 4 * (cb / 4) : 0))) * 4;
+			};
+			const size_t lds = std::max(lds_of(P), tail_ok ? lds_of(PT) : 0);
+			if (lds > 48 * 1024) HIP_TRY(h, hipFuncSetAttribute((const void *)wf, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+			/* the main units' walkers: persistent wavefronts, AT_WALK_WAVES_PER_CU (1) per CU at most, that refill their lanes from a counter
+			 * (the word behind the sweep's work counter); the sliver's: one wavefront per 128 alignments */
+			const long long wmain = std::max<long long>(1, std::min<long long>((nm + 127) / 128, env_ll("AT_WALK_WAVES_PER_CU", 1) * h->ncu));
+			HIP_TRY(h, hipMemsetAsync(h->d_queue + 8, 0, 16, stream));
+			hipLaunchKernelGGL(wf, dim3((unsigned)(wmain + (n_tail + 127) / 128)), dim3(64), lds, stream, b, bt);
+			HIP_TRY(h, hipGetLastError());
+		}
 		if (n_tail > 0)
 			snprintf(h->cfg + strlen(h->cfg), sizeof h->cfg - strlen(h->cfg), " + last %lld pairs as 32-lane items (rows/lane=%d)", (long long)n_tail, PT.k);
+		if (first == 0) cfg_first = h->cfg;
+		}
+		if (piece < npairs) snprintf(h->cfg, sizeof h->cfg, "%.200s; in pieces of %lld pairs", cfg_first.c_str(), (long long)piece);
 		return AT_OK;
 	}
 
@@ -1014,7 +1080,7 @@ static int align_device(at_handle *h, int mode, int64_t npairs,
 		m.score = d_score; m.end_i = d_end_i; m.end_j = d_end_j; m.state = d_state; m.nops = d_nops;
 		m.order = d_order;
 		m.ap_n = ap_n; m.ap_first = ap_first;
-		if (!h->d_queue) HIP_TRY(h, hipMalloc((void **)&h->d_queue, 64));
+		if (!h->d_queue) HIP_TRY(h, hipMalloc((void **)&h->d_queue, 128));
 		HIP_TRY(h, hipMemsetAsync(h->d_queue, 0, 8, stream));
 		m.queue = h->d_queue;
 		const size_t lds = myers_windows(per_wave);   /* (odd window stride, as the kernel computes it) */
@@ -1056,7 +1122,7 @@ static int align_device(at_handle *h, int mode, int64_t npairs,
 			m.ap_n = ap_n; m.ap_first = ap_first;
 			m.semi_m2 = 2 * h->m; m.semi_k = (int)k2; m.semi_min2 = (int)std::max<long long>(std::min<long long>(2LL * h->min_score, INT32_MAX), INT32_MIN);
 			m.cand_order = cand; m.cand_count = count;
-			if (!h->d_queue) { HIP_TRY(h, hipMalloc((void **)&h->d_queue, 64)); HIP_TRY(h, hipMemset(h->d_queue, 0, 64)); }
+			if (!h->d_queue) { HIP_TRY(h, hipMalloc((void **)&h->d_queue, 128)); HIP_TRY(h, hipMemset(h->d_queue, 0, 128)); }
 			HIP_TRY(h, hipMemsetAsync(h->d_queue, 0, 8, stream));
 			m.queue = h->d_queue;
 			const size_t lds = windows(64);

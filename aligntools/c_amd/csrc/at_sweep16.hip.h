@@ -95,6 +95,14 @@ struct Sweep16Args {
 	/* two-pass tracebacks (CK kernels, see replay16_block): regions of the per-wave global slot, word offsets --
 	 * border row 0, row checkpoints, column checkpoints, the replayed blocks' pointer words (+ jump plane) */
 	int off_brow, off_rck, off_cck, off_rptr, off_rjpl;
+	/* ... with pass 2 as a kernel of its own (at_walk16.hip.h): the checkpoints of work item w of this launch go to ck + w * ck_item_words
+	 * instead of the wave's slot (off_rck / off_cck count from there), row 0 of the matrix -- the same for every alignment of the
+	 * batch -- to ck_brow, and every alignment's end cell, state and verdict to tp_end; the sweep then ends where the rounds would
+	 * begin.  ck = nullptr: the rounds run inside the sweep's kernel. */
+	uint32_t *ck;
+	long long ck_item_words;
+	uint32_t *ck_brow;
+	int4 *tp_end;
 };
 
 AT_DEV uint32_t pk2(int v) { return ((uint32_t)v & 0xffffu) | ((uint32_t)v << 16); }
@@ -259,6 +267,9 @@ AT_DEV int pidx(int wr, int r, int lane, int NL)
 #define AT_CK_STEPS64 32  /* ... on the 64-lane group (its LDS holds a staging area of 33 steps): half the column checkpoints of the forward
                            * sweep, half the block visits of a walk, 4.3 rounds per C3 alignment instead of 7.1 -- C3 2 987 -> 3 159 GCUPS */
 #endif
+#ifndef AT_TP_WAVES64
+#define AT_TP_WAVES64 2   /* wavefronts per SIMD the two-pass kernels of the 64-lane group are compiled for */
+#endif
 #ifndef AT_CK_W64
 #define AT_CK_W64 3       /* t-blocks per band of a round on the 64-lane group */
 #endif
@@ -266,6 +277,34 @@ constexpr int ck_steps(int g) { return g == 64 ? AT_CK_STEPS64 : AT_CK_STEPS; }
 template <int MODE> constexpr int ck_es() { return MODE == K_FITJ ? 4 : 3; }                     /* words of a row checkpoint entry */
 template <int MODE, int K> constexpr int ck_nq() { return ((MODE == K_FITJ ? 3 : 2) * K + 3) / 4; }   /* 16-byte chunks of a column checkpoint */
 constexpr int ck_log2(int v) { return v <= 1 ? 0 : 1 + ck_log2(v / 2); }
+/* Where the checkpoints lie (words from off_rck / off_cck).  The sweep produces them step by step, 64 lanes at a time; a replay (the walk
+ * kernel's above all: one walker per half-lane, every lane somewhere else) reads CB + 1 consecutive steps of ONE lane and one lane's column
+ * checkpoint.  [step][lane], the sweep's own order, makes every entry a replay reads a cache line of its own (17 + 10 lines for 360 bytes
+ * on the 8-lane groups: the walk kernels of C3 fetched as many bytes as the sweep wrote).  So:
+ *   row checkpoints     entry 0 of every lane first (the border), then TILES of AT_CK_ROW_TILE (4) steps: [tile][lane][step][ES words] --
+ *                       a replay reads 5 (9) lines where it read 17 (33); the sweep's store of one step is 64 x 12 bytes, 48 bytes apart
+ *                       (whole tiles of CB steps cost the sweep 17 .. 29 %: every store 64 lines)
+ *   column checkpoints  [c][chunk / Q][lane][chunk % Q] with Q = AT_CK_COL_QUAD (4) chunks of 16 bytes adjacent */
+#ifndef AT_CK_ROW_TILE
+#define AT_CK_ROW_TILE 4
+#endif
+#ifndef AT_CK_COL_QUAD
+#define AT_CK_COL_QUAD 4
+#endif
+template <int ES>
+AT_DEV int ck_rck_word(int e, int slot_lane)   /* entry e = the state after step e - 1 */
+{
+	constexpr int RT = AT_CK_ROW_TILE;
+	const int t = e - 1;
+	return e <= 0 ? slot_lane * ES : 64 * ES + ((t / RT) * 64 + slot_lane) * (RT * ES) + (t % RT) * ES;
+}
+template <int ES> constexpr int ck_rck_step() { return AT_CK_ROW_TILE > 1 ? ES : 64 * ES; }   /* words between the entries of two steps of one tile */
+template <int NQ>
+AT_DEV int ck_cck_word(int c, int slot_lane, int q)
+{
+	constexpr int Q = AT_CK_COL_QUAD, NQQ = (NQ + Q - 1) / Q;
+	return (((c * NQQ + q / Q) * 64 + slot_lane) * Q + q % Q) * 4;
+}
 
 /* Which blocks a round replays for one alignment, seen from its walker's cell (ci, cj) -- the anchor.  Band b = the lane
  * that owns row ci, t = (cj - 1) + band = the step at which that lane swept column cj, t-block c = t / CB.
@@ -409,9 +448,8 @@ AT_REPLAY_FN void replay16_block(const Sweep16Args &a, const Slot<SMALL> &mem, u
 	const int i0A = blA * K, i0B = blB * K;
 	/* row checkpoint entries of the row above my band: band 0 reads the border row (entry = column), the others the lane above
 	 * (entry e = state after step e - 1).  p = the entry of step org - 1 -- the cell diagonally above my first one */
-	const int sA = blA == 0 ? ES : 64 * ES, sB = blB == 0 ? ES : 64 * ES;
-	const int pA = blA == 0 ? a.off_brow + orgA * ES : a.off_rck + ((orgA - 1) * 64 + grp * G + blA - 1) * ES;
-	const int pB = blB == 0 ? a.off_brow + orgB * ES : a.off_rck + ((orgB - 1) * 64 + grp * G + blB - 1) * ES;
+	auto entA = [&](int x) { return blA == 0 ? a.off_brow + (orgA + x) * ES : a.off_rck + ck_rck_word<ES>(orgA - 1 + x, grp * G + blA - 1); };
+	auto entB = [&](int x) { return blB == 0 ? a.off_brow + (orgB + x) * ES : a.off_rck + ck_rck_word<ES>(orgB - 1 + x, grp * G + blB - 1); };
 	/* ---- the row above my two blocks, CB + 1 entries from step org - 1 on, staged in LDS as the lane below sees it: X' = max(L, M,
 	 *      U[, J]) with the winner's tag, and L of the row below = max(L + e, M + o).  All loads are issued before the state arrays
 	 *      exist (registers are free now) and cost one round trip; the step loop then reads two words per step from LDS. ---- */
@@ -420,7 +458,7 @@ AT_REPLAY_FN void replay16_block(const Sweep16Args &a, const Slot<SMALL> &mem, u
 		typedef typename std::conditional<ES == 4, uint4, ck_u3>::type ent_t;
 		ent_t ra[CB + 1], rb[CB + 1];
 #pragma unroll
-		for (int x = 0; x <= CB; ++x) { ra[x] = *(const ent_t *)(gs + pA + x * sA); rb[x] = *(const ent_t *)(gs + pB + x * sB); }
+		for (int x = 0; x <= CB; ++x) { ra[x] = *(const ent_t *)(gs + entA(x)); rb[x] = *(const ent_t *)(gs + entB(x)); }
 #pragma unroll
 		for (int x = 0; x <= CB; ++x) {
 			const uint32_t eL = lohi(ra[x].x, rb[x].x), eM = lohi(ra[x].y, rb[x].y), eU = lohi(ra[x].z, rb[x].z);
@@ -441,7 +479,7 @@ AT_REPLAY_FN void replay16_block(const Sweep16Args &a, const Slot<SMALL> &mem, u
 	}
 	{
 		/* the column checkpoint's values (M + o of my K rows, then U, then J: untagged) straight into the state arrays */
-		const int ckA = a.off_cck + (cA * NQ * 64 + grp * G + blA) * 4, ckB = a.off_cck + (cB * NQ * 64 + grp * G + blB) * 4;
+		const int ckA = a.off_cck, ckB = a.off_cck;
 		auto put = [&](auto XC, uint32_t val) {
 			constexpr int x = decltype(XC)::value;
 			if constexpr (x < K) Mo_l[x] = val;
@@ -450,7 +488,7 @@ AT_REPLAY_FN void replay16_block(const Sweep16Args &a, const Slot<SMALL> &mem, u
 		};
 		uint4 cva[NQ], cvb[NQ];
 #pragma unroll
-		for (int q = 0; q < NQ; ++q) { cva[q] = *(const uint4 *)(gs + ckA + q * 256); cvb[q] = *(const uint4 *)(gs + ckB + q * 256); }
+		for (int q = 0; q < NQ; ++q) { cva[q] = *(const uint4 *)(gs + ckA + ck_cck_word<NQ>(cA, grp * G + blA, q)); cvb[q] = *(const uint4 *)(gs + ckB + ck_cck_word<NQ>(cB, grp * G + blB, q)); }
 		auto chunk = [&](auto QC) {
 			constexpr int q = decltype(QC)::value;
 			const uint4 va = cva[q], vb = cvb[q];
@@ -603,9 +641,11 @@ AT_REPLAY_FN void replay16_block(const Sweep16Args &a, const Slot<SMALL> &mem, u
 
 /* The work items [wbase, wbase + items of `a`) of one launch, pulled from the launch's work counter: `wnext` is the item this wave
  * holds when it gets here (its block index, or what an earlier call left over); returns the first item beyond the range. */
-template <int MODE, int G, int K, int TS, bool SMALL, bool PTRLDS, bool TB, bool RAG = false, int BITS = 2, int CK = 0>
+template <int MODE, int G, int K, int TS, bool SMALL, bool PTRLDS, bool TB, bool RAG = false, int BITS = 2, int CK = 0, bool SPLIT = false>
 AT_DEV long long sweep16_items(const Sweep16Args &a, long long wnext, const long long wbase)
 {
+	/* SPLIT: pass 2 of the two-pass tracebacks is a kernel of its own (at_walk16.hip.h): this one ends where the rounds would begin */
+	static_assert(!SPLIT || CK > 0, "a walk kernel follows a sweep that leaves checkpoints");
 	/* CK > 0: two-pass tracebacks -- the scores-only sweep leaves checkpoints every CK steps, the pointers are rebuilt block by block
 	 * where the walks need them (replay16_block above) */
 	constexpr bool TP = CK > 0;
@@ -690,16 +730,17 @@ AT_DEV long long sweep16_items(const Sweep16Args &a, long long wnext, const long
 	const int refoff = grp * 2 * a.off_refb;  /* my group's two s2 byte arrays */
 	/* two-pass tracebacks: this wave's slot holds the checkpoints; row 0 of the matrix, the same for every alignment of the batch, is
 	 * written once as the row checkpoint of a lane above lane 0: entry j = (L, M, U[, J]) of cell (0, j) */
-	uint32_t *const gs = TP ? a.ws + (long long)blockIdx.x * a.ws_slot_words : nullptr;
+	uint32_t *gs = TP ? a.ws + (long long)blockIdx.x * a.ws_slot_words : nullptr;
 	constexpr int ES = ck_es<MODE>();
 	const int ck_T = tbk_frame * BLK;         /* steps of a sweep */
 	(void)gs; (void)ck_T;
 	if constexpr (TP) {
+		uint32_t *const brow = SPLIT ? a.ck_brow : gs + a.off_brow;   /* (split: every wave writes the batch's one copy, the same words) */
 		for (int j = lane; j <= l2; j += 64) {
 			int L, M, U;
 			border16<MODE>(0, j, o16, e16, L, M, U);
-			gs[a.off_brow + j * ES] = pk2(sat16(L)); gs[a.off_brow + j * ES + 1] = pk2(M); gs[a.off_brow + j * ES + 2] = pk2(U);
-			if constexpr (ES == 4) gs[a.off_brow + j * ES + 3] = 0x80008000u;
+			brow[j * ES] = pk2(sat16(L)); brow[j * ES + 1] = pk2(M); brow[j * ES + 2] = pk2(U);
+			if constexpr (ES == 4) brow[j * ES + 3] = 0x80008000u;
 		}
 	}
 
@@ -709,6 +750,7 @@ AT_DEV long long sweep16_items(const Sweep16Args &a, long long wnext, const long
 		(void)st_item;
 		if (TP && AT_TP_STATS) st_item = (long long)__builtin_amdgcn_s_memtime();
 		wnext = next_work(a.queue, lane);   /* consumed at the end of this work item: latency hidden */
+		if constexpr (TP && SPLIT) gs = a.ck + wk * a.ck_item_words;
 		const long long last = a.npairs - 1;
 		long long pA = (wk * NG + grp) * 2 < a.npairs ? (wk * NG + grp) * 2 : last;
 		long long pB = (wk * NG + grp) * 2 + 1 < a.npairs ? (wk * NG + grp) * 2 + 1 : last;
@@ -852,14 +894,15 @@ AT_DEV long long sweep16_items(const Sweep16Args &a, long long wnext, const long
 			}
 			/* two-pass: (L, M, U[, J]) of my last row as of my latest step -- the border's until my first one; entry 0 of my row checkpoints */
 			uint32_t ckL = 0, ckM = 0, ckU = 0, ckJ = neg2;
-			int ck_p = a.off_rck + lane * ES;      /* where the entry of the current step goes */
+			int ck_p = 0;                          /* where the entries of the current block of steps go (ck_rck_word: all in one chunk) */
 			(void)ckL; (void)ckM; (void)ckU; (void)ckJ; (void)ck_p;
 			if constexpr (TP) {
 				int L, M, U;
 				border16<MODE>(i0 + K, 0, o16, e16, L, M, U);
 				ckL = pk2(sat16(L)); ckM = pk2(M); ckU = pk2(U);
-				gs[ck_p] = ckL; gs[ck_p + 1] = ckM; gs[ck_p + 2] = ckU;
-				if constexpr (ES == 4) gs[ck_p + 3] = ckJ;
+				const int p0 = a.off_rck + ck_rck_word<ES>(0, lane);
+				gs[p0] = ckL; gs[p0 + 1] = ckM; gs[p0 + 2] = ckU;
+				if constexpr (ES == 4) gs[p0 + 3] = ckJ;
 			}
 			uint32_t A_prev = Xl[0][K - 1], B_prev = 0, Ad;
 			{
@@ -883,6 +926,7 @@ AT_DEV long long sweep16_items(const Sweep16Args &a, long long wnext, const long
 
 			for (int blk = 0; blk < tbk; ++blk) {
 				const int t0 = blk * BLK;
+				if constexpr (TP) ck_p = a.off_rck + ck_rck_word<ES>(t0 + 1, lane);
 				load_bound(t0 + BLK, bxn, bln);
 				/* ---- s2 windows: bytes t0-lg .. t0-lg+7 of both alignments ---- */
 				uint32_t wA[2], wB[2];
@@ -1119,9 +1163,11 @@ AT_DEV long long sweep16_items(const Sweep16Args &a, long long wnext, const long
 					Ad = Aup;
 					if constexpr (TP) {
 						/* row checkpoint entry t + 1: my last row after this step (a step outside the matrix repeats the entry before) */
-						ck_p += 64 * ES;
-						if constexpr (ES == 4) *(uint4 *)(gs + ck_p) = make_uint4(ckL, ckM, ckU, ckJ);
-						else { gs[ck_p] = ckL; gs[ck_p + 1] = ckM; gs[ck_p + 2] = ckU; }
+						static_assert(!TP || AT_CK_ROW_TILE <= 1 || BLK % AT_CK_ROW_TILE == 0, "a tile of row checkpoints lies in one block of steps");
+						constexpr int RT = AT_CK_ROW_TILE > 1 ? AT_CK_ROW_TILE : 1;
+						constexpr int so = (k / RT) * 64 * RT * ES + (k % RT) * ck_rck_step<ES>();   /* (t0 is a multiple of the tile: step k lies k / RT tiles on) */
+						if constexpr (ES == 4) *(uint4 *)(gs + ck_p + so) = make_uint4(ckL, ckM, ckU, ckJ);
+						else { gs[ck_p + so] = ckL; gs[ck_p + so + 1] = ckM; gs[ck_p + so + 2] = ckU; }
 					}
 					if constexpr (TB) {
 						if constexpr (OVL && PB == 2) {
@@ -1197,7 +1243,7 @@ AT_DEV long long sweep16_items(const Sweep16Args &a, long long wnext, const long
 					/* column checkpoint c: (M + o, U[, J]) of my K rows after step c * CK - 1, in 16-byte chunks [c][chunk][lane] */
 					if ((t0 + BLK) % CK == 0) {
 						constexpr int NV = HASJ ? 3 : 2, NQ = ck_nq<MODE, K>();
-						const int cb = a.off_cck + (((t0 + BLK) / CK) * NQ * 64 + lane) * 4;
+						const int cb = a.off_cck, cidx = (t0 + BLK) / CK;
 						auto val = [&](auto XC) -> uint32_t {
 							constexpr int x = decltype(XC)::value;
 							if constexpr (x < K) return Mo_l[x];
@@ -1207,7 +1253,7 @@ AT_DEV long long sweep16_items(const Sweep16Args &a, long long wnext, const long
 						};
 						auto chunk = [&](auto QC) {
 							constexpr int q = decltype(QC)::value;
-							*(uint4 *)(gs + cb + q * 256) = make_uint4(val(std::integral_constant<int, 4 * q>{}), val(std::integral_constant<int, 4 * q + 1>{}),
+							*(uint4 *)(gs + cb + ck_cck_word<NQ>(cidx, lane, q)) = make_uint4(val(std::integral_constant<int, 4 * q>{}), val(std::integral_constant<int, 4 * q + 1>{}),
 							                                          val(std::integral_constant<int, 4 * q + 2>{}), val(std::integral_constant<int, 4 * q + 3>{}));
 						};
 						static_for<NQ>(chunk);
@@ -1301,7 +1347,17 @@ AT_DEV long long sweep16_items(const Sweep16Args &a, long long wnext, const long
 			}
 			my_sc = sc16; my_ci = ci; my_cj = cj; my_st = st; my_ok = ok;
 		}
-		if constexpr (TP) {
+		if constexpr (TP && SPLIT) {
+			/* ================= two-pass tracebacks, pass 2 a kernel of its own (at_walk16.hip.h): leave what it starts from ================= */
+			const long long pin = wk * 2 * NG + lane;
+			if (lane < 2 * NG && pin < a.npairs) {
+				a.score[pin] = my_ok ? (my_sc >> TS) : INT32_MIN;
+				if (a.end_i) a.end_i[pin] = my_ci;
+				if (a.end_j) a.end_j[pin] = my_cj;
+				if (a.state) a.state[pin] = my_st == 3 ? 1 : my_st == 2 ? 2 : 3;
+				a.tp_end[pin] = make_int4(my_ci, my_cj, my_st, my_ok ? 1 : 0);
+			}
+		} else if constexpr (TP) {
 			/* ================= two-pass tracebacks: rounds of { replay the blocks the walks are heading for; walk } ================= */
 			constexpr int LCB = ck_log2(CK);
 			constexpr int KG2 = (K + 3) / 4;
@@ -1319,8 +1375,8 @@ AT_DEV long long sweep16_items(const Sweep16Args &a, long long wnext, const long
 			CkPattern<G, K, CK> pat;
 			(void)KG2;
 			long long st_t0 = 0, st_rep = 0, st_walk = 0;
-			int st_rounds = 0, st_fetch = 0;
-			(void)st_t0; (void)st_rep; (void)st_walk; (void)st_rounds; (void)st_fetch;
+			int st_rounds = 0, st_fetch = 0, st_iters = 0;
+			(void)st_t0; (void)st_rep; (void)st_walk; (void)st_rounds; (void)st_fetch; (void)st_iters;
 			if (AT_TP_STATS) st_t0 = (long long)__builtin_amdgcn_s_memtime();
 			for (int rounds = 0;; ++rounds) {
 				/* has my walk arrived?  local: HOME (:788-791) or a border; global: a border (then the padding loops); fit: row 0 */
@@ -1457,10 +1513,13 @@ AT_DEV long long sweep16_items(const Sweep16Args &a, long long wnext, const long
 									/* while its state does not change a walk keeps its direction (LOW up, MID diagonal, UPP left) and its op: the cells of
 									 * the next four ops along it are read together; n of them are consumed -- up to the first one that changes the state,
 									 * the block's edge, the end of the ops slot */
-									const int inL = st == 3, inM = st == 2;
-									const int di = inL | inM, dj = inL ^ 1;
-									/* (the state machine in bit arithmetic: written with selects hipcc makes branches of it, and a wait between the reads) */
-									const uint32_t mL = 0u - (uint32_t)inL, mM = 0u - (uint32_t)inM, mU = ~(mL | mM);
+									if (AT_TP_STATS) ++st_iters;
+									/* (the state machine without compares: written with selects hipcc makes branches of it and puts a wait between the four
+									 * reads; written with compares every result crosses from the vector unit to a scalar mask and back.  st is 1, 2 or 3 here) */
+									const uint32_t ust = (uint32_t)st;
+									const uint32_t inL = ust & (ust >> 1), inM = (ust >> 1) & ~ust & 1u;   /* st == 3, st == 2 */
+									const int di = (int)(ust >> 1), dj = (int)(inL ^ 1u);
+									const uint32_t mL = 0u - inL, mM = 0u - inM, mU = ~(mL | mM);
 									uint32_t nbv[4], nst[4];
 									int shv[4];
 #pragma unroll
@@ -1477,17 +1536,18 @@ AT_DEV long long sweep16_items(const Sweep16Args &a, long long wnext, const long
 										const uint32_t lres = 2u + ((nb >> 2) & 1u), mres = nb & 3u, ures = TS == 4 ? 1u + ((nb >> 3) & 1u) : 2u - ((nb >> 3) & 1u);
 										nst[x] = (lres & mL) | (mres & mM) | (ures & mU);
 									}
-									const uint32_t ust = (uint32_t)st;
-									const int e0 = nst[0] == ust, e1 = e0 & (nst[1] == ust), e2 = e1 & (nst[2] == ust);
-									const int lim = imin(imin(di ? rr : 3, dj ? ss : 3), own_len - cnt - 1);       /* ops beyond the first that stay inside */
-									const int n = imin(1 + e0 + e1 + e2, lim + 1);
-									const uint32_t op4 = ((uint32_t)inL | (2u & mU)) * 0x01010101u;      /* LOW 1, MID 0, UPP 2 */
+									/* e_x = 1 while the state stays what it was: ((a ^ b) - 1) >> 31 is a == b */
+									const uint32_t e0 = ((nst[0] ^ ust) - 1u) >> 31, e1 = e0 & (((nst[1] ^ ust) - 1u) >> 31), e2 = e1 & (((nst[2] ^ ust) - 1u) >> 31);
+									const int mdi = -di, mdj = -dj;
+									const int lim = imin(imin((rr & mdi) | (3 & ~mdi), (ss & mdj) | (3 & ~mdj)), own_len - cnt - 1);   /* ops beyond the first that stay inside */
+									const int n = imin(1 + (int)(e0 + e1 + e2), lim + 1);
+									const uint32_t op4 = (inL | (2u & mU)) * 0x01010101u;                  /* LOW 1, MID 0, UPP 2 */
 									if (__builtin_expect(cnt + 4 <= own_len, 1)) __builtin_memcpy(ops + cnt, &op4, 4);   /* (bytes behind the walk's end are rewritten or never read) */
 									else {
 #pragma nounroll
 										for (int x = 0; x < n; ++x) ops[cnt + x] = (uint8_t)op4;
 									}
-									st = (int)(n == 1 ? nst[0] : n == 2 ? nst[1] : n == 3 ? nst[2] : nst[3]);
+									st = (int)(((nst[0] | (nst[1] << 4) | (nst[2] << 8) | (nst[3] << 12)) >> (4 * (n - 1))) & 15u);
 									ci -= n * di; cj -= n * dj; cnt += n;
 								}
 								if constexpr (NBLK == 1) break;
@@ -1510,12 +1570,14 @@ AT_DEV long long sweep16_items(const Sweep16Args &a, long long wnext, const long
 			if (AT_WALK_PRIO) __builtin_amdgcn_s_setprio(0);
 			if (AT_TP_STATS) {
 				const long long now = (long long)__builtin_amdgcn_s_memtime();
-				int mxf = st_fetch;
+				int mxf = st_fetch, mxi = st_iters;
+				for (int d = 1; d < 64; d <<= 1) mxi = imax(mxi, __shfl_xor(mxi, d));
 				if (lane == 0) {
 					atomicAdd(a.queue + 1, 1ull); atomicAdd(a.queue + 2, (unsigned long long)st_rounds);
 					atomicAdd(a.queue + 3, (unsigned long long)st_walk); atomicAdd(a.queue + 4, (unsigned long long)mxf);
 					atomicAdd(a.queue + 5, (unsigned long long)(now - st_t0)); atomicAdd(a.queue + 6, (unsigned long long)st_rep);
-					atomicAdd(a.queue + 7, (unsigned long long)(st_t0 - st_item));
+					if (AT_TP_STATS == 2) atomicAdd(a.queue + 7, (unsigned long long)mxi);
+					else atomicAdd(a.queue + 7, (unsigned long long)(st_t0 - st_item));
 				}
 			}
 			if (mine) {
@@ -1715,16 +1777,16 @@ constexpr int at_tail_k(int g, int k)
  * long) that follow the main items in the same work queue -- a launch that has the chip to itself then ends with a fifth of the
  * SIMDs busy for a short item instead of a tenth of them working through one long item more (C2: 6 250 items of 16 pairs on 2 048
  * resident waves = 3.05 rounds).  t.npairs = 0: no sliver.  Other kernels ignore `t`. */
-template <int MODE, int G, int K, int TS, bool SMALL, bool PTRLDS, bool TB, bool RAG = false, int BITS = 2, int CK = 0>
-__global__ __launch_bounds__(64, (CK > 0 && G == 64 ? 2 : AT_WAVES16(G, K))) void at_sweep16(const Sweep16Args a, const Sweep16Args t)
+template <int MODE, int G, int K, int TS, bool SMALL, bool PTRLDS, bool TB, bool RAG = false, int BITS = 2, int CK = 0, bool SPLIT = false>
+__global__ __launch_bounds__(64, (CK > 0 && G == 64 ? AT_TP_WAVES64 : AT_WAVES16(G, K))) void at_sweep16(const Sweep16Args a, const Sweep16Args t)
 {
 	if (a.only_if && __builtin_amdgcn_readfirstlane(*a.only_if) != a.only_val) return;
-	long long w = sweep16_items<MODE, G, K, TS, SMALL, PTRLDS, TB, RAG, BITS, CK>(a, (long long)blockIdx.x, 0);
+	long long w = sweep16_items<MODE, G, K, TS, SMALL, PTRLDS, TB, RAG, BITS, CK, SPLIT>(a, (long long)blockIdx.x, 0);
 	if constexpr (G <= 16 && !RAG && MODE != K_OVERLAP) {
 		if (t.npairs > 0) {
 			constexpr int NGm = 64 / G;
 			const long long nmain = (a.npairs + 2 * NGm - 1) / (2 * NGm);
-			sweep16_items<MODE, AT_TAIL_G, at_tail_k(G, K), TS, SMALL, PTRLDS, TB, false, BITS, CK>(t, w, nmain);
+			sweep16_items<MODE, AT_TAIL_G, at_tail_k(G, K), TS, SMALL, PTRLDS, TB, false, BITS, CK, SPLIT>(t, w, nmain);
 		}
 	}
 }

@@ -898,7 +898,8 @@ static int align_device(at_handle *h, int mode, int64_t npairs,
 	 * By default where that wins -- the 64-lane groups with 16 rows per lane (reads of 609 .. 1 024 bases: the one-pass kernels hold 4 rows
 	 * per lane there and need four strips); AT_TWO_PASS=2: wherever a CK kernel exists (the 8-lane groups x 19 rows lose: C2 -7 %, C4
 	 * -28 %, profiles/r04/two_pass_ab.txt), AT_TWO_PASS=0: never (A/B runs) */
-	bool two_pass = false, tp_split = false;
+	bool two_pass = false;
+	int tp_split = 0;   /* pass 2: 0 the rounds inside the sweep's kernel, 1 a walk kernel behind it */
 	const long long tp_mode = env_ll("AT_TWO_PASS", 1);
 	if (ts && tb && !rag && kmode <= at::K_FITJ && tp_mode) {
 		Layout16 P2 = layout16_for(false, kmode == at::K_FITJ, max_len1, max_len2, ts, 0, false, kmode, 0, 1);
@@ -907,7 +908,7 @@ static int align_device(at_handle *h, int mode, int64_t npairs,
 			two_pass = true;
 			/* pass 2 as a kernel of its own (at_walk16.hip.h): the sweep leaves its checkpoints per work item, one walker per half-lane
 			 * replays the blocks its walk crosses.  AT_TP_SPLIT=0: the rounds inside the sweep's kernel (A/B runs) */
-			tp_split = env_ll("AT_TP_SPLIT", 1) && at_pick_walk16(kmode, P2.g, P2.k, ts, bits) != nullptr;
+			tp_split = env_ll("AT_TP_SPLIT", 0) && at_pick_walk16(kmode, P2.g, P2.k, ts, bits) ? 1 : 0;
 			if (tp_split) P2 = layout16_for(false, kmode == at::K_FITJ, max_len1, max_len2, ts, 0, false, kmode, 0, 2);
 			P = P2;
 		}
@@ -920,7 +921,7 @@ static int align_device(at_handle *h, int mode, int64_t npairs,
 		Layout16 PT = P;
 		if (tail_ok) PT = layout16_for(tb && !two_pass, kmode == at::K_FITJ, max_len1, max_len2, ts, at::AT_TAIL_G, false, kmode, at::at_tail_k(P.g, P.k), two_pass ? (tp_split ? 2 : 1) : 0);
 		TpLayout tpm{}, tpt{};
-		if (two_pass) { tpm = tp_layout(P, kmode, max_len2, tp_split); tpt = tp_layout(PT, kmode, max_len2, tp_split); }
+		if (two_pass) { tpm = tp_layout(P, kmode, max_len2, tp_split != 0); tpt = tp_layout(PT, kmode, max_len2, tp_split != 0); }
 		/* split two-pass: the checkpoints of a whole launch live side by side -- C2 225 KB, C3 / C4 1.1 MB per work item -- so a batch is
 		 * swept and walked in pieces whose checkpoints fit AT_CK_CAP_MB (8 192) */
 		int64_t piece = npairs;
@@ -933,6 +934,14 @@ static int align_device(at_handle *h, int mode, int64_t npairs,
 			if (items < 1) return fail(h, AT_ERR_NOMEM, "two-pass tracebacks: one work item's checkpoints (%lld bytes) exceed AT_CK_CAP_MB", tpm.words * 4);
 			piece = std::min<int64_t>(npairs, items * per_wave);
 		}
+		auto walk_lane_words = [&](const Layout16 &L) -> long long {   /* a walker lane's pointer words of one block (at_walk16.hip.h) */
+			const int cb = at::ck_steps(L.g);
+			return L.k * (cb / 4) + (kmode == at::K_FITJ ? (L.k + 3) / 4 * (cb / 4) : 0);
+		};
+		auto walk_lds = [&](const Layout16 &L, bool ptr_in_lds) -> size_t {
+			const int cb = at::ck_steps(L.g), nsm = kmode == at::K_FITJ ? L.nsm : 0;
+			return (size_t)((nsm + 1) / 2 * 2 + (cb + 1) * 128 + (ptr_in_lds ? 64 * walk_lane_words(L) : 0)) * 4;
+		};
 		std::string cfg_first;
 		for (int64_t first = 0; first < npairs; first += piece) {
 		const int64_t np = std::min<int64_t>(piece, npairs - first);
@@ -1034,11 +1043,7 @@ static int align_device(at_handle *h, int mode, int64_t npairs,
 		if (tp_split && !env_ll("AT_DIAG_NO_WALK_KERNEL", 0)) {   /* (1: throw-away runs without pass 2 -- what does the sweep alone reach?  Every pair reports garbage ops) */
 			at_walk16_fn wf = at_pick_walk16(kmode, P.g, P.k, ts, bits);
 			if (!wf) return fail(h, AT_ERR_RANGE, "no walk kernel for %d-lane groups x %d rows", P.g, P.k);
-			auto lds_of = [&](const Layout16 &L) {
-				const int cb = at::ck_steps(L.g), nsm = kmode == at::K_FITJ ? L.nsm : 0;
-				return (size_t)((nsm + 1) / 2 * 2 + (cb + 1) * 128 + 64 * (L.k * (cb / 4) + (kmode == at::K_FITJ ? (L.k + 3) / 4 * (cb / 4) : 0))) * 4;
-			};
-			const size_t lds = std::max(lds_of(P), tail_ok ? lds_of(PT) : 0);
+			const size_t lds = std::max(walk_lds(P, true), tail_ok ? walk_lds(PT, true) : 0);
 			if (lds > 48 * 1024) HIP_TRY(h, hipFuncSetAttribute((const void *)wf, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
 			/* the main units' walkers: persistent wavefronts, AT_WALK_WAVES_PER_CU (1) per CU at most, that refill their lanes from a counter
 			 * (the word behind the sweep's work counter); the sliver's: one wavefront per 128 alignments */

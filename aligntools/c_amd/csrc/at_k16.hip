@@ -15,8 +15,8 @@
 	at_sweep16_fn at_pick16_rag16b_b##b(int kmode, int k, int store, bool tb);     \
 	at_sweep16_fn at_pick16_rag32_b##b(int kmode, int k, int store, bool tb);      \
 	at_sweep16_fn at_pick16_ragovl_b##b(int k, int store);                           \
-	at_sweep16_fn at_pick16_tp8_b##b(int kmode, int k, bool split);                            \
-	at_sweep16_fn at_pick16_tp64_b##b(int kmode, int k, int ts, bool split);                 \
+	at_sweep16_fn at_pick16_tp8_b##b(int kmode, int k, int split);                             \
+	at_sweep16_fn at_pick16_tp64_b##b(int kmode, int k, int ts, int split);                  \
 	at_walk16_fn at_pick_walk16_g8_b##b(int kmode, int g, int k);                    \
 	at_walk16_fn at_pick_walk16_g64_b##b(int kmode, int k, int ts);
 AT_DECL(2)
@@ -49,7 +49,7 @@ at_sweep16_fn at_pick16_rag(int kmode, int g, int k, int store, bool tb, int bit
 	return bits == 8 ? at_pick16_rag16_b8(kmode, k, store, tb) : at_pick16_rag16_b2(kmode, k, store, tb);
 }
 /* two-pass traceback kernels (CK): global slot for the checkpoints, LDS for the s2 windows */
-at_sweep16_fn at_pick16_tp(int kmode, int g, int k, int ts, int bits, bool split)
+at_sweep16_fn at_pick16_tp(int kmode, int g, int k, int ts, int bits, int split)
 {
 	if (g == 8) return ts != 4 ? nullptr : bits == 8 ? at_pick16_tp8_b8(kmode, k, split) : at_pick16_tp8_b2(kmode, k, split);
 	if (g == 64) return bits == 8 ? at_pick16_tp64_b8(kmode, k, ts, split) : at_pick16_tp64_b2(kmode, k, ts, split);

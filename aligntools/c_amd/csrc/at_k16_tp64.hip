@@ -2,15 +2,15 @@
 /* two-pass traceback kernels (at_sweep16.hip.h, CK), one group of 64 lanes x 16 rows in one strip (reads of up to 1 024 bases: C3),
  * scores x4 or x16.  (fit -s with scores x4 keeps byte cells in the one-pass kernels and has no two-pass form.) */
 template <int MODE, int TS>
-static at_sweep16_fn tp64(int k, bool split)
+static at_sweep16_fn tp64(int k, int split)
 {
 	switch (k) {
-	case 16: return split ? at::at_sweep16<MODE, 64, 16, TS, true, false, false, false, AT_BITS16, at::ck_steps(64), true>
+	case 16: return split ? at::at_sweep16<MODE, 64, 16, TS, true, false, false, false, AT_BITS16, at::ck_steps(64), 1>
 	                      : at::at_sweep16<MODE, 64, 16, TS, true, false, false, false, AT_BITS16, at::ck_steps(64)>;
 	default: return nullptr;
 	}
 }
-at_sweep16_fn AT_NAME(at_pick16_tp64)(int kmode, int k, int ts, bool split)
+at_sweep16_fn AT_NAME(at_pick16_tp64)(int kmode, int k, int ts, int split)
 {
 	if (ts == 2) {
 		switch (kmode) {

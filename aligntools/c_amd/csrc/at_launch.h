@@ -15,7 +15,7 @@ at_sweep_fn at_pick32_b2(int kmode, int k, int store, bool tb);
 at_sweep_fn at_pick32_b8(int kmode, int k, int store, bool tb);
 at_sweep16_fn at_pick16_rag(int kmode, int g, int k, int store, bool tb, int bits);   /* ragged frames: g in {8, 16} */
 at_sweep16_fn at_pick16(int kmode, int g, int k, int ts, int store, bool tb, int bits);
-at_sweep16_fn at_pick16_tp(int kmode, int g, int k, int ts, int bits, bool split = false);   /* two-pass tracebacks (CK kernels; split: pass 2 is a kernel of its own), or nullptr */
+at_sweep16_fn at_pick16_tp(int kmode, int g, int k, int ts, int bits, int split = 0);   /* two-pass tracebacks (CK kernels; split = 1: pass 2 is a kernel of its own), or nullptr */
 typedef void (*at_walk16_fn)(const at::Sweep16Args, const at::Sweep16Args);   /* (launch, its sliver) */
 at_walk16_fn at_pick_walk16(int kmode, int g, int k, int ts, int bits);   /* their pass 2 as a kernel of its own (at_walk16.hip.h), or nullptr */
 /* every packed translation unit is compiled twice: -DAT_BITS16=2 (16 codes per sequence word, score LUT) and

@@ -641,10 +641,10 @@ AT_REPLAY_FN void replay16_block(const Sweep16Args &a, const Slot<SMALL> &mem, u
 
 /* The work items [wbase, wbase + items of `a`) of one launch, pulled from the launch's work counter: `wnext` is the item this wave
  * holds when it gets here (its block index, or what an earlier call left over); returns the first item beyond the range. */
-template <int MODE, int G, int K, int TS, bool SMALL, bool PTRLDS, bool TB, bool RAG = false, int BITS = 2, int CK = 0, bool SPLIT = false>
+template <int MODE, int G, int K, int TS, bool SMALL, bool PTRLDS, bool TB, bool RAG = false, int BITS = 2, int CK = 0, int SPLIT = 0>
 AT_DEV long long sweep16_items(const Sweep16Args &a, long long wnext, const long long wbase)
 {
-	/* SPLIT: pass 2 of the two-pass tracebacks is a kernel of its own (at_walk16.hip.h): this one ends where the rounds would begin */
+	/* SPLIT = 1: pass 2 of the two-pass tracebacks is a kernel of its own (at_walk16.hip.h): this one ends where the rounds would begin */
 	static_assert(!SPLIT || CK > 0, "a walk kernel follows a sweep that leaves checkpoints");
 	/* CK > 0: two-pass tracebacks -- the scores-only sweep leaves checkpoints every CK steps, the pointers are rebuilt block by block
 	 * where the walks need them (replay16_block above) */
@@ -1777,7 +1777,7 @@ constexpr int at_tail_k(int g, int k)
  * long) that follow the main items in the same work queue -- a launch that has the chip to itself then ends with a fifth of the
  * SIMDs busy for a short item instead of a tenth of them working through one long item more (C2: 6 250 items of 16 pairs on 2 048
  * resident waves = 3.05 rounds).  t.npairs = 0: no sliver.  Other kernels ignore `t`. */
-template <int MODE, int G, int K, int TS, bool SMALL, bool PTRLDS, bool TB, bool RAG = false, int BITS = 2, int CK = 0, bool SPLIT = false>
+template <int MODE, int G, int K, int TS, bool SMALL, bool PTRLDS, bool TB, bool RAG = false, int BITS = 2, int CK = 0, int SPLIT = 0>
 __global__ __launch_bounds__(64, (CK > 0 && G == 64 ? AT_TP_WAVES64 : AT_WAVES16(G, K))) void at_sweep16(const Sweep16Args a, const Sweep16Args t)
 {
 	if (a.only_if && __builtin_amdgcn_readfirstlane(*a.only_if) != a.only_val) return;

@@ -1514,11 +1514,14 @@ def test_host_entry_writes_only_its_slots(al):
     ("global", False, 129, 140, 500, (1, -1, -1, -1, -10), []),
     ("fit", True, 140, 300, 500, (1, -1, -1, -1, -2), [7, 50, 51, 120]),
 ])
-def test_two_pass_tracebacks(al, case, monkeypatch):
+@pytest.mark.parametrize("walk_kernel", [0, 1])
+def test_two_pass_tracebacks(al, case, walk_kernel, monkeypatch):
     """Two-pass tracebacks (at_sweep16.hip.h, CK kernels: the scores-only sweep leaves checkpoints, the pointers are rebuilt block by
     block where the walks go) against the one-pass kernels on the whole batch -- score, end cell, start state, ops -- and against the
-    oracle on a sample; related and unrelated pairs, batches that leave the last work item partly empty."""
+    oracle on a sample; related and unrelated pairs, batches that leave the last work item partly empty.  walk_kernel = 1: pass 2 as a
+    kernel of its own (at_walk16.hip.h, AT_TP_SPLIT=1: one walker per half-lane)."""
     mode, uj, l1, l2, n, sc, sites = case
+    monkeypatch.setenv("AT_TP_SPLIT", str(walk_kernel))
     rng = random.Random(l1 * 7919 + l2)
 
     def mk(related):
@@ -1542,7 +1545,7 @@ def test_two_pass_tracebacks(al, case, monkeypatch):
     monkeypatch.setenv("AT_HOST_CHUNKS", "1")
     monkeypatch.setenv("AT_TWO_PASS", "2")
     two = al.align_batch(mode, pairs, traceback=True, render=False)
-    assert "two-pass" in al.last_config, al.last_config
+    assert "two-pass" in al.last_config and ("walk kernel" in al.last_config) == bool(walk_kernel), al.last_config
     monkeypatch.setenv("AT_TWO_PASS", "0")
     one = al.align_batch(mode, pairs, traceback=True, render=False)
     assert "two-pass" not in al.last_config, al.last_config
@@ -1550,6 +1553,68 @@ def test_two_pass_tracebacks(al, case, monkeypatch):
         assert (np.asarray(two[key]) == np.asarray(one[key])).all(), (case, key)
     assert two["ops"] == one["ops"], case
     for k in range(0, len(pairs), max(1, len(pairs) // (12 if l1 > 300 else 60))):
+        r = O.align(O.MODE_NAMES[mode], pairs[k][0], pairs[k][1], *sc, uj, sites)
+        assert (int(two["score"][k]), int(two["end_i"][k]), int(two["end_j"][k]), int(two["state"][k])) == \
+               (r["score"], r["end_i"], r["end_j"], r["state"]), (case, k)
+        assert two["ops"][k] == r["ops"], (case, k)
+
+
+@pytest.mark.parametrize("case", [
+    # mode, jump state, l1, l2, pairs, scoring, sites, alphabet, AT_CK_CAP_MB: what it reaches
+    ("local", False, 150, 150, 20000, (2, -2, -5, -2, -10), [], "ACGT", 1100),          # a batch in pieces (the checkpoints of ~8 000 pairs fit the cap)
+    ("local", False, 150, 150, 33408, (2, -2, -5, -2, -10), [], "ACGT", 0),             # a sliver of 640 pairs on two 32-lane groups x 5 rows, walked by the first wavefronts
+    ("fit", True, 150, 500, 33088, (2, -2, -5, -1, -10), [100, 200, 300, 400], "ACGT", 0),   # ... with the jump state
+    ("global", False, 150, 150, 701, (1, -1, -1, -1, -10), [], "ACGTN", 0),             # byte words (reads with N): the _b8 kernels; an odd batch
+    ("local", False, 1000, 1024, 257, (1, -1, -1, -1, -10), [], "ACGTN", 0),            # ... on the 64-lane group; the last lane holds one alignment
+    ("global", False, 150, 150, 1, (2, -2, -5, -2, -10), [], "ACGT", 0),                # one alignment
+])
+def test_two_pass_walk_kernel_batches(al, case, monkeypatch):
+    """Pass 2 as a kernel of its own (AT_TP_SPLIT=1, at_walk16.hip.h): batches cut into pieces by the checkpoint cap, batches that end with
+    a sliver on 32-lane groups, byte alphabets, odd and tiny batches -- the whole batch against the one-pass kernels, a sample against the
+    oracle."""
+    mode, uj, l1, l2, n, sc, sites, alpha, cap = case
+    rng = random.Random(l1 * 31 + l2 + n)
+
+    def mk(related):
+        a = "".join(rng.choice(alpha) for _ in range(l1))
+        if not related:
+            return a, "".join(rng.choice(alpha) for _ in range(l2))
+        t = list(a)
+        for _ in range(1 + l1 // 12):
+            q = rng.randrange(len(t))
+            r = rng.random()
+            if r < 0.5:
+                t[q] = rng.choice(alpha)
+            elif r < 0.75 and len(t) > 1:
+                del t[q]
+            else:
+                t.insert(q, rng.choice(alpha))
+        return a, ("".join(rng.choice(alpha) for _ in range(rng.randint(0, max(0, l2 - l1)))) + "".join(t) + "".join(rng.choice(alpha) for _ in range(l2)))[:l2]
+
+    uniq = [mk(k % 3 != 0) for k in range(min(n, 397))]
+    pairs = (uniq * (n // len(uniq) + 1))[:n]
+    al.set_scoring(*sc, uj, sites)
+    monkeypatch.setenv("AT_HOST_CHUNKS", "1")
+    monkeypatch.setenv("AT_TWO_PASS", "2")
+    monkeypatch.setenv("AT_TP_SPLIT", "1")
+    if cap:
+        monkeypatch.setenv("AT_CK_CAP_MB", str(cap))
+    two = al.align_batch(mode, pairs, traceback=True, render=False)
+    cfg = al.last_config
+    assert "walk kernel" in cfg, cfg
+    if cap:
+        assert "in pieces of" in cfg, cfg
+    if n > 33000:
+        assert "as 32-lane items" in cfg, cfg
+    if "N" in alpha:
+        assert "bits=8" in cfg, cfg
+    monkeypatch.setenv("AT_TWO_PASS", "0")
+    one = al.align_batch(mode, pairs, traceback=True, render=False)
+    assert "two-pass" not in al.last_config, al.last_config
+    for key in ("score", "end_i", "end_j", "state", "nops"):
+        assert (np.asarray(two[key]) == np.asarray(one[key])).all(), (case, key)
+    assert two["ops"] == one["ops"], case
+    for k in list(range(0, min(n, len(uniq)), 9)) + [n - 1]:
         r = O.align(O.MODE_NAMES[mode], pairs[k][0], pairs[k][1], *sc, uj, sites)
         assert (int(two["score"][k]), int(two["end_i"][k]), int(two["end_j"][k]), int(two["state"][k])) == \
                (r["score"], r["end_i"], r["end_j"], r["state"]), (case, k)

@@ -8,7 +8,7 @@ mkdir -p $D/pmc $D/pmc_scores
 cp $S/traffic_*.json $S/valu_issue.json $S/valu_issue.txt $D/ 2>/dev/null || true
 for f in workloads_bench.jsonl two_pass_ab.jsonl c2_driver_style_bench.json c2_streams1_bench.json c2_under_rocprof_bench.json c2_streams1_under_rocprof_bench.json \
          c3_under_rocprof_bench.json c4_under_rocprof_bench.json host_path_rate.txt batch_cli_rate.txt ragged_rate.txt pcie_rate.txt cli_latency.txt \
-         dist_nccl1.json dist_gloo2_C4_self_launched.json; do [ -f $S/$f ] && cp $S/$f $D/; done
+         dist_nccl1.json dist_gloo2_C4_self_launched.json walk_kernel_stats_rocprof.txt C2_trace.txt C3_trace.txt; do [ -f $S/$f ] && cp $S/$f $D/; done
 for f in $S/*kernel_stats.csv; do [ -f "$f" ] && (head -1 $f; grep "at::at_" $f) > $D/$(basename $f); done
 for sub in pmc pmc_scores; do for f in $S/$sub/*.csv; do [ -f "$f" ] && (head -1 $f; grep "at::at_" $f) > $D/$sub/$(basename $f); done; done
 for f in pytest_gpu_final.log smoke.log full_size_bench.jsonl fuzz_parity.txt; do [ -f $Q/$f ] && cp $Q/$f $D/; done

@@ -8,9 +8,9 @@ O=gpurun_out/$1; ENVS=$(echo "$2" | tr ',' ' '); WLS=$3; shift 3
 mkdir -p $O
 for e in $ENVS; do export $e; done
 for W in $WLS; do
-  (cd /tmp && rocprofv3 --kernel-trace --stats -d $R/$O/stats_$W -o k --output-format csv -- python3 $R/bench.py --workload $W --no-cpu-baseline --streams 1 "$@" > $R/$O/${W}_bench.json 2> $R/$O/${W}_rocprof.err) || true
+  (cd /tmp && rocprofv3 --kernel-trace --stats -d $R/$O/stats_$W -o k --output-format csv -- python3 $R/bench.py --workload $W --no-cpu-baseline --streams 1 "$@" > $R/$O/walk_${W}_bench.json 2> $R/$O/walk_${W}_rocprof.err) || true
   f=$(find $O/stats_$W -name '*kernel_stats.csv' | head -1)
-  [ -n "$f" ] && cp $f $O/${W}_kernel_stats.csv && python3 - "$f" <<'PY'
+  [ -n "$f" ] && (head -1 $f; grep 'at::at_' $f) > $O/walk_${W}_kernel_stats.csv && python3 - "$f" <<'PY'
 import csv,sys
 rows=list(csv.DictReader(open(sys.argv[1])))
 for r in rows[:8]:

@@ -1,5 +1,5 @@
 #!/bin/bash
-# profiles.sh ROUND -- everything profiles/<ROUND>/ is made of, on one MI355X (through gpurun from the repo root; ~15 minutes):
+# profiles.sh ROUND [main|ab|all] -- everything profiles/<ROUND>/ is made of, on one MI355X (through gpurun from the repo root; ~15 minutes):
 # the issue-rate microbenchmark, PMC counters of every workload's sweep kernel (separate --pmc passes), bench lines priced with
 # them (CPU baseline included), rocprofv3 kernel stats, the two-pass A/B, host-inclusive rates, N > 1 rehearsals.
 # Results land in gpurun_out/<ROUND>p; tools/copy_profiles.sh ROUND copies what is to be committed into profiles/<ROUND>/.
@@ -7,8 +7,11 @@ set -e
 export TMPDIR=/tmp
 R=$PWD
 RD=${1:-r04}
+PART=${2:-all}     # main: counters, bench lines, rocprofv3 stats, host rates, rehearsals; ab: the two-pass A/B and the walk kernel's stats (gpurun's limit is 20 minutes a call)
 O=gpurun_out/${RD}p
-rm -rf $O; mkdir -p $O/pmc $O/pmc_scores profiles/$RD
+[ $PART != ab ] && rm -rf $O
+mkdir -p $O/pmc $O/pmc_scores profiles/$RD
+if [ $PART != ab ]; then
 [ -x tools/bin/valu_issue ] || { mkdir -p tools/bin; /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 tools/valu_issue.hip -o tools/bin/valu_issue; }
 tools/bin/valu_issue $O/valu_issue.json > $O/valu_issue.txt
 echo "valu_issue done"
@@ -29,13 +32,22 @@ done
 timeout -k 10 300 python3 bench.py --workload C5all --steps 60 --no-cpu-baseline --min-score 30 >> $O/workloads_bench.jsonl 2>> $O/bench.err
 timeout -k 10 300 python3 bench.py --gpus 1 --steps 20 --warmup 5 > $O/c2_driver_style_bench.json 2>> $O/bench.err
 timeout -k 10 300 python3 bench.py --streams 1 --steps 60 --no-cpu-baseline > $O/c2_streams1_bench.json 2>> $O/bench.err
-# two-pass tracebacks against the one-pass kernels, same box: launches in flight and one launch at a time (AT_TWO_PASS: 0 never, 1 default
-# routing -- the 64-lane groups x 16 rows --, 2 wherever a CK kernel exists)
+fi
+if [ $PART != main ]; then
+# two-pass tracebacks against the one-pass kernels, same box: launches in flight (3, 4) and one launch at a time.  AT_TWO_PASS: 0 never,
+# 1 default routing -- the 64-lane groups x 16 rows --, 2 wherever a CK kernel exists; AT_TP_SPLIT=1: pass 2 as a kernel of its own
+# (at_walk16.hip.h); AT_DIAG_NO_WALK_KERNEL=1: the sweep with checkpoints alone (no pass 2: what a free pass 2 would reach)
 : > $O/two_pass_ab.jsonl
-for W in C2 C3 C4; do for TP in 0 1 2; do for S in 3 1; do
-  AT_TWO_PASS=$TP timeout -k 10 300 python3 bench.py --workload $W --steps 30 --warmup 5 --streams $S --no-cpu-baseline | python3 -c "
-import json,sys; d=json.loads(sys.stdin.read()); print(json.dumps({'workload':'$W','AT_TWO_PASS':$TP,'streams':$S,'gcups':round(d['value'],1),'ms_per_step':round(d['ms_per_step'],4),'kernel_config':d['config']['kernel_config']}))" >> $O/two_pass_ab.jsonl 2>> $O/bench.err
+for W in C2 C3 C4; do for V in "0 0 0" "1 0 0" "2 0 0" "2 1 0" "2 1 1"; do set -- $V; for S in 3 4 1; do
+  AT_TWO_PASS=$1 AT_TP_SPLIT=$2 AT_DIAG_NO_WALK_KERNEL=$3 timeout -k 10 300 python3 bench.py --workload $W --steps 30 --warmup 5 --streams $S --no-cpu-baseline | python3 -c "
+import json,sys; d=json.loads(sys.stdin.read()); print(json.dumps({'workload':'$W','AT_TWO_PASS':$1,'AT_TP_SPLIT':$2,'sweep_only':$3,'streams':$S,'gcups':round(d['value'],1),'ms_per_step':round(d['ms_per_step'],4),'kernel_config':d['config']['kernel_config']}))" >> $O/two_pass_ab.jsonl 2>> $O/bench.err
 done; done; done
+# where a launch of the walk-kernel form spends its time: rocprofv3 kernel stats one launch at a time, the start / end of every launch with three in flight
+bash tools/gpu/kstats.sh ${RD}p AT_TWO_PASS=2,AT_TP_SPLIT=1 "C2 C3 C4" --steps 20 > $O/walk_kernel_stats_rocprof.txt 2>> $O/bench.err || true
+for W in C2 C3; do bash tools/gpu/ktrace.sh ${RD}p AT_TWO_PASS=2,AT_TP_SPLIT=1 $W --steps 20 > /dev/null 2>> $O/bench.err || true; done
+echo "two-pass A/B done"
+fi
+[ $PART = ab ] && exit 0
 echo "bench done"
 (cd /tmp && rocprofv3 --kernel-trace --stats -d $R/$O/stats -o c2 --output-format csv -- python3 $R/bench.py --no-cpu-baseline > $R/$O/c2_under_rocprof_bench.json 2> $R/$O/rocprof.err) || true
 (cd /tmp && rocprofv3 --kernel-trace --stats -d $R/$O/stats1 -o c2s1 --output-format csv -- python3 $R/bench.py --no-cpu-baseline --streams 1 > $R/$O/c2_streams1_under_rocprof_bench.json 2>> $R/$O/rocprof.err) || true

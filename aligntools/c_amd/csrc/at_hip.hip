@@ -90,6 +90,7 @@ struct at_handle {
 	uint32_t *d_sitemask = nullptr; size_t sitemask_words = 0; int sitemask_for_l2 = -1; bool sitemask_dirty = true;
 	uint32_t *d_ws = nullptr; size_t ws_bytes = 0;
 	uint32_t *d_ck = nullptr; size_t ck_bytes = 0;   /* two-pass tracebacks with a walk kernel: a launch's checkpoints */
+	bool ck_alloc_failed = false;                    /* ... could not be allocated once: this handle keeps to the rounds inside the sweep's kernel */
 	unsigned long long *d_queue = nullptr;
 	int last_span = 0;              /* max_len1 + max_len2 of the handle's latest batch: the rendering kernel's hint for its group width */
 	void *d_in = nullptr; size_t in_bytes = 0;
@@ -907,8 +908,10 @@ static int align_device(at_handle *h, int mode, int64_t npairs,
 		    choose_store(P2.off_ptr, 1, true) == 1) {
 			two_pass = true;
 			/* pass 2 as a kernel of its own (at_walk16.hip.h): the sweep leaves its checkpoints per work item, one walker per half-lane
-			 * replays the blocks its walk crosses.  AT_TP_SPLIT=0: the rounds inside the sweep's kernel (A/B runs) */
-			tp_split = env_ll("AT_TP_SPLIT", 0) && at_pick_walk16(kmode, P2.g, P2.k, ts, bits) ? 1 : 0;
+			 * replays the blocks its walk crosses.  AT_TP_SPLIT=0: the rounds inside the sweep's kernel */
+			/* by default on the 64-lane groups, where teams of walker lanes cut the chain of rounds (C3 2 900 -> 3 900 GCUPS with launches
+			 * in flight, 2 660 -> 3 150 one at a time); AT_TP_SPLIT=1: wherever a walk kernel exists, 0: nowhere */
+			tp_split = env_ll("AT_TP_SPLIT", P2.g == 64 ? 1 : 0) && !h->ck_alloc_failed && at_pick_walk16(kmode, P2.g, P2.k, ts, bits) ? 1 : 0;
 			if (tp_split) P2 = layout16_for(false, kmode == at::K_FITJ, max_len1, max_len2, ts, 0, false, kmode, 0, 2);
 			P = P2;
 		}
@@ -1028,6 +1031,14 @@ static int align_device(at_handle *h, int mode, int64_t npairs,
 			void *pc = h->d_ck; size_t have = h->ck_bytes;
 			rc = grow(h, &pc, &have, need);
 			h->d_ck = (uint32_t *)pc; h->ck_bytes = have;
+			if (rc && first == 0) {
+				/* no room for a launch's checkpoints (several handles on one card, a small AT_CK_CAP_MB would have cut the batch into pieces):
+				 * nothing has been launched yet -- the same batch with the rounds inside the sweep's kernel, whose checkpoints live in the
+				 * resident wavefronts' slots */
+				h->ck_alloc_failed = true;
+				return align_device(h, mode, npairs, d_seq, bits, d_woff1, d_len1, d_woff2, d_len2, max_len1, max_len2, uniform_shape, want_traceback,
+				                    d_score, d_end_i, d_end_j, d_state, d_ops, d_ops_off, d_nops, stream_, ap_n, ap_first, d_order, rag, only_if, only_val);
+			}
 			if (rc) return rc;
 			b.ck_brow = h->d_ck; bt.ck_brow = h->d_ck;
 			b.tp_end = (int4 *)(h->d_ck + brow_words); bt.tp_end = b.tp_end + nm;
@@ -1041,7 +1052,9 @@ static int align_device(at_handle *h, int mode, int64_t npairs,
 		hipLaunchKernelGGL(fn16, dim3((unsigned)pl.grid), dim3(64), pl.dyn_lds, stream, b, bt);
 		HIP_TRY(h, hipGetLastError());
 		if (tp_split && !env_ll("AT_DIAG_NO_WALK_KERNEL", 0)) {   /* (1: throw-away runs without pass 2 -- what does the sweep alone reach?  Every pair reports garbage ops) */
-			at_walk16_fn wf = at_pick_walk16(kmode, P.g, P.k, ts, bits);
+			/* the 64-lane groups: teams of lanes per pair of alignments (walk16_team_wave; AT_WALK_TEAMS=0: one walker per half-lane there too) */
+			const bool teams = P.g == 64 && env_ll("AT_WALK_TEAMS", 1) && at_pick_walk16(kmode, P.g, P.k, ts, bits, 1);
+			at_walk16_fn wf = at_pick_walk16(kmode, P.g, P.k, ts, bits, teams);
 			if (!wf) return fail(h, AT_ERR_RANGE, "no walk kernel for %d-lane groups x %d rows", P.g, P.k);
 			const size_t lds = std::max(walk_lds(P, true), tail_ok ? walk_lds(PT, true) : 0);
 			if (lds > 48 * 1024) HIP_TRY(h, hipFuncSetAttribute((const void *)wf, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
@@ -1049,7 +1062,8 @@ static int align_device(at_handle *h, int mode, int64_t npairs,
 			 * (the word behind the sweep's work counter); the sliver's: one wavefront per 128 alignments */
 			const long long wmain = std::max<long long>(1, std::min<long long>((nm + 127) / 128, env_ll("AT_WALK_WAVES_PER_CU", 1) * h->ncu));
 			HIP_TRY(h, hipMemsetAsync(h->d_queue + 8, 0, 16, stream));
-			hipLaunchKernelGGL(wf, dim3((unsigned)(wmain + (n_tail + 127) / 128)), dim3(64), lds, stream, b, bt);
+			const long long wteams = ((nm + 1) / 2 + 64 / at_walk16_team_lanes() - 1) / (64 / at_walk16_team_lanes());
+			hipLaunchKernelGGL(wf, dim3((unsigned)(teams ? wteams : wmain + (n_tail + 127) / 128)), dim3(64), lds, stream, b, bt);
 			HIP_TRY(h, hipGetLastError());
 		}
 		if (n_tail > 0)

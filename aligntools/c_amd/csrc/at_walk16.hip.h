@@ -43,8 +43,12 @@ template <int MODE, int K, int TS, int BITS, int CB>
 AT_DEV void replay16_lane(const Sweep16Args &a, const uint32_t *giA, const uint32_t *giB, const int lane0A, const int lane0B,
                           const uint32_t *qA, const uint32_t *qB, const uint32_t *rA, const uint32_t *rB,
                           const int blA, const int cA, const int blB, const int cB,
-                          const int SM0, const int S0, const int P0, const int PJ0)
+                          const int SM0, const int S0, const int P0, const int PJ0, long long *stt = nullptr)
 {
+	/* (stt: -DAT_TP_STATS=2 -- cycles until the first loads are staged, of the state's set-up, of the step loop) */
+	long long stt0 = 0;
+	(void)stt0;
+	if (AT_TP_STATS == 2) stt0 = (long long)__builtin_amdgcn_s_memtime();
 	constexpr bool HASJ = MODE == K_FITJ;
 	static_assert(!HASJ || (TS == 4 && AT_JPLANE), "two-pass jump state: scores x16, 4-bit cells + bit plane");
 	static_assert(MODE == K_GLOBAL || MODE == K_LOCAL || MODE == K_FIT || MODE == K_FITJ, "two-pass tracebacks: the affine modes");
@@ -145,6 +149,7 @@ AT_DEV void replay16_lane(const Sweep16Args &a, const uint32_t *giA, const uint3
 		for (int x = 0; x < NWQ0; ++x) { qwa[x] = qA[imin(wqa0 + x, lwq0)]; qwb[x] = qB[imin(wqb0 + x, lwq0)]; }
 		stage1(seedA, seedB, 0);
 		stage(1);
+		if (AT_TP_STATS == 2) { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); const long long n = (long long)__builtin_amdgcn_s_memtime(); stt[0] += n - stt0; stt0 = n; }
 		if constexpr (CB > PH) ask(1 + PH);
 		if constexpr (BITS == 2) {
 			const int sha = (jA0 & 15) * 2, shb = (jB0 & 15) * 2;
@@ -160,44 +165,58 @@ AT_DEV void replay16_lane(const Sweep16Args &a, const uint32_t *giA, const uint3
 		/* the query words my bands' rows lie in (a band of K rows spans NWQ sequence words at most), fetched together */
 		constexpr int LBP = LBP0, NWQ = NWQ0;
 		const int wqa = wqa0, wqb = wqb0;
+		/* (blocks that start at their lane's first step, from the border, are a few per walk: the border's values are worked out only when
+		 * some lane of the wavefront has one) */
+		const bool some_border = __any(mck != 0xffffffffu);
+		auto setup = [&](auto BORDER) {
+			constexpr bool border = decltype(BORDER)::value;
 #pragma unroll
-		for (int r = 0; r < K; ++r) {
-			const uint32_t vMo = Mo_l[r], vU = U_l[r];
-			uint32_t vJ = neg2;
-			if constexpr (HASJ) vJ = J_l[r];
-			int La, Ma, Ua, Lb, Mb, Ub;
-			border16<MODE>(i0A + r + 1, 0, o16, e16, La, Ma, Ua);
-			border16<MODE>(i0B + r + 1, 0, o16, e16, Lb, Mb, Ub);
-			La = sat16(La); Lb = sat16(Lb);
-			const uint32_t bMo = pk2h(sat16((Ma | TGM) + o16), sat16((Mb | TGM) + o16));
-			const uint32_t bU = pk2h(Ua | TGU, Ub | TGU);
-			const uint32_t bX = pk2h(imax3(La | TGL, Ma | TGM, Ua | TGU), imax3(Lb | TGL, Mb | TGM, Ub | TGU));
-			/* from the checkpoint: M + o and U as stored (untagged), L by the chain down the column */
-			const uint32_t kMo = vMo | cTagM, kU = vU | cTagU;
-			const uint32_t Lc = lraw | cTagL, Mc = psub(vMo, o2) | cTagM;
-			uint32_t kX = pmax(pmax(Lc, Mc), kU);
-			if constexpr (HASJ) kX = pmax(kX, vJ);
-			lraw = pmax(padd(Lc, e2), kMo);
-			Mo_l[r] = vbfi(mck, kMo, bMo);
-			U_l[r] = vbfi(mck, kU, bU);
-			Xl[0][r] = vbfi(mck, kX, bX);
-			Xl[1][r] = Xl[0][r];
-			if constexpr (HASJ) J_l[r] = vbfi(mck, vJ, neg2);
-			/* my query bases, per half its own band's rows */
-			const int qi = imin(i0A + r, l1 - 1), qj = imin(i0B + r, l1 - 1);
-			const uint32_t wa = pick<NWQ>(qwa, (qi >> LBP) - wqa), wb = pick<NWQ>(qwb, (qj >> LBP) - wqb);
-			uint32_t ca, cb;
-			if constexpr (BITS == 2) { ca = (wa >> ((qi & 15) * 2)) & 3u; cb = (wb >> ((qj & 15) * 2)) & 3u; }
-			else { ca = (wa >> ((qi & 3) * 8)) & 0xffu; cb = (wb >> ((qj & 3) * 8)) & 0xffu; }
-			qsel[r] = (ca * 0x00000101u + cb * 0x01010000u) | (BITS == 2 ? 0x04000400u : 0u);
-			acc[r] = 0;
-		}
+			for (int r = 0; r < K; ++r) {
+				const uint32_t vMo = Mo_l[r], vU = U_l[r];
+				uint32_t vJ = neg2;
+				if constexpr (HASJ) vJ = J_l[r];
+				/* from the checkpoint: M + o and U as stored (untagged), L by the chain down the column */
+				const uint32_t kMo = vMo | cTagM, kU = vU | cTagU;
+				const uint32_t Lc = lraw | cTagL, Mc = psub(vMo, o2) | cTagM;
+				uint32_t kX = pmax(pmax(Lc, Mc), kU);
+				if constexpr (HASJ) kX = pmax(kX, vJ);
+				lraw = pmax(padd(Lc, e2), kMo);
+				if constexpr (border) {
+					int La, Ma, Ua, Lb, Mb, Ub;
+					border16<MODE>(i0A + r + 1, 0, o16, e16, La, Ma, Ua);
+					border16<MODE>(i0B + r + 1, 0, o16, e16, Lb, Mb, Ub);
+					La = sat16(La); Lb = sat16(Lb);
+					const uint32_t bMo = pk2h(sat16((Ma | TGM) + o16), sat16((Mb | TGM) + o16));
+					const uint32_t bU = pk2h(Ua | TGU, Ub | TGU);
+					const uint32_t bX = pk2h(imax3(La | TGL, Ma | TGM, Ua | TGU), imax3(Lb | TGL, Mb | TGM, Ub | TGU));
+					Mo_l[r] = vbfi(mck, kMo, bMo);
+					U_l[r] = vbfi(mck, kU, bU);
+					Xl[0][r] = vbfi(mck, kX, bX);
+					if constexpr (HASJ) J_l[r] = vbfi(mck, vJ, neg2);
+				} else {
+					Mo_l[r] = kMo; U_l[r] = kU; Xl[0][r] = kX;
+					if constexpr (HASJ) J_l[r] = vJ;
+				}
+				Xl[1][r] = Xl[0][r];
+				/* my query bases, per half its own band's rows */
+				const int qi = imin(i0A + r, l1 - 1), qj = imin(i0B + r, l1 - 1);
+				const uint32_t wa = pick<NWQ>(qwa, (qi >> LBP) - wqa), wb = pick<NWQ>(qwb, (qj >> LBP) - wqb);
+				uint32_t ca, cb;
+				if constexpr (BITS == 2) { ca = (wa >> ((qi & 15) * 2)) & 3u; cb = (wb >> ((qj & 15) * 2)) & 3u; }
+				else { ca = (wa >> ((qi & 3) * 8)) & 0xffu; cb = (wb >> ((qj & 3) * 8)) & 0xffu; }
+				qsel[r] = (ca * 0x00000101u + cb * 0x01010000u) | (BITS == 2 ? 0x04000400u : 0u);
+				acc[r] = 0;
+			}
+		};
+		if (some_border) setup(std::true_type{});
+		else setup(std::false_type{});
 	}
 	if constexpr (HASJ) {
 #pragma unroll
 		for (int g = 0; g < KG; ++g) { jA[g] = 0; jB[g] = 0; }
 	}
 
+	if (AT_TP_STATS == 2) { const long long n = (long long)__builtin_amdgcn_s_memtime(); stt[1] += n - stt0; stt0 = n; }
 	for (int s4 = 0; s4 < CB / 4; ++s4) {
 		if constexpr (CB > PH) {
 			/* a phase begins (not the first): its entries have arrived -- stage them, ask for the next phase's */
@@ -227,11 +246,13 @@ AT_DEV void replay16_lane(const Sweep16Args &a, const uint32_t *giA, const uint3
 			smA = __builtin_amdgcn_alignbit(at_lds[SM0 + (eA >> 5) + 1], at_lds[SM0 + (eA >> 5)], eA & 31);
 			smB = __builtin_amdgcn_alignbit(at_lds[SM0 + (eB >> 5) + 1], at_lds[SM0 + (eB >> 5)], eB & 31);
 		}
+		uint2 eup4[4];                     /* (the four reads together: one LDS latency per four steps instead of one per step) */
+#pragma unroll
+		for (int k = 0; k < 4; ++k) eup4[k] = *reinterpret_cast<const uint2 *>(&at_lds[stg + (1 + 4 * s4 + k) * 128]);
 		auto step = [&](auto KC) {
 			constexpr int k = decltype(KC)::value;
 			constexpr uint32_t SELK = (uint32_t)k * 0x00000101u + (uint32_t)(4 + k) * 0x01010000u;
-			const uint2 eup = *reinterpret_cast<const uint2 *>(&at_lds[stg + (1 + 4 * s4 + k) * 128]);   /* the row above in this step's column */
-			const uint32_t Aup = eup.x, Bup = eup.y;
+			const uint32_t Aup = eup4[k].x, Bup = eup4[k].y;                     /* the row above in this step's column */
 			uint32_t gopen = neg2;
 			if constexpr (HASJ) gopen = lohi(((smA >> k) & 1u) ? gmo2 : neg2, ((smB >> k) & 1u) ? gmo2 : neg2);
 			const uint32_t selw = __builtin_amdgcn_perm(wB, wA, SELK);
@@ -297,6 +318,85 @@ AT_DEV void replay16_lane(const Sweep16Args &a, const uint32_t *giA, const uint3
 			for (int g = 0; g < KG; ++g) at_lds[PJ0 + (s4 * KG + g) * 64 + lane] = jA[g] | (jB[g] >> 1);
 		}
 	}
+	if (AT_TP_STATS == 2) { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); stt[2] += (long long)__builtin_amdgcn_s_memtime() - stt0; }
+}
+
+/* One walker inside the block (bl, c) whose pointer words lie in column `src` of LDS (half h of every word): while its state does not
+ * change a walk keeps its direction (LOW up, MID diagonal, UPP / JUMP left) and its op: the cells of the next four ops along it are
+ * read together; n of them are consumed -- up to the first one that changes the state, the block's edge, the end of the ops slot */
+template <int MODE, int K, int TS, int CB>
+AT_DEV void walk16_block(const int h, const int src, int &wci, int &wcj, int &wst, int &wcnt, uint8_t *wops, const int own_len,
+                         const int bl, const int c, const int P0, const int PJ0)
+{
+	constexpr bool HASJ = MODE == K_FITJ;
+	constexpr int LCB = ck_log2(CB), KG = (K + 3) / 4;
+	(void)KG;
+	const int i_lo = bl * K, t_lo = imax(c << LCB, bl) - bl;   /* row (0-based) and column - 1 of the block's first cell */
+	for (;;) {
+		/* inside the block both offsets are >= 0.  st = 0: HOME, or a corrupt pointer (the round loop sorts it out), or the jump state */
+		const int rr = wci - 1 - i_lo, ss = wcj - 1 - t_lo;
+		if ((rr | ss) < 0 || wcnt >= own_len || (wst == 0 && !HASJ)) break;
+		if constexpr (HASJ) {
+			if (wst == 0) {
+				/* jump state (:579-583): left along the row until the column where J opened from M.  A plane word holds my row's
+				 * bits of 4 steps, {step 1, step 3, step 0, step 2}; up to 4 words -- 16 columns -- put in column order, the steps
+				 * behind mine shifted out: the first set bit is where J opened */
+				constexpr unsigned long long ORD = 0xfbea7362d9c85140ull;
+				const int s4 = ss >> 2, tk = ss & 3;
+				uint32_t cols = 0;
+#pragma unroll
+				for (int x = 0; x < 4; ++x) {
+					const uint32_t w = at_lds[PJ0 + (imax(s4 - x, 0) * KG + (rr >> 2)) * 64 + src];
+					const uint32_t nib = (w >> (16 * h + cell_shift<4>(rr & 3))) & 15u;
+					cols = (cols << 4) | ((uint32_t)(ORD >> (4 * nib)) & 15u);
+				}
+				cols = (cols << (3 - tk)) & 0xffffu;                         /* bit 15 = column cj */
+				const int avail = 4 * imin(4, s4 + 1) - (3 - tk);          /* columns of this block from mine leftwards */
+				const int lim = imin(imin(avail, wcj), own_len - wcnt);
+				const int n = __clz((int)((cols << 16) | 0x8000u));
+				const int steps = n < lim ? n + 1 : lim;
+				if (n < lim) wst = 2;
+				for (int x = 0; x < steps; ++x) wops[wcnt + x] = 3;
+				wcnt += steps; wcj -= steps;
+				continue;
+			}
+		}
+		/* (the state machine without compares: written with selects hipcc makes branches of it and puts a wait between the four
+		 * reads.  st is 1, 2 or 3 here) */
+		const uint32_t ust = (uint32_t)wst;
+		const uint32_t inL = ust & (ust >> 1), inM = (ust >> 1) & ~ust & 1u;   /* st == 3, st == 2 */
+		const int di = (int)(ust >> 1), dj = (int)(inL ^ 1u);
+		const uint32_t mL = 0u - inL, mM = 0u - inM, mU = ~(mL | mM);
+		uint32_t nbv[4], nst[4];
+		int shv[4];
+#pragma unroll
+		for (int x = 0; x < 4; ++x) {
+			const int rx = imax(rr - x * di, 0), sx = imax(ss - x * dj, 0);
+			nbv[x] = at_lds[P0 + ((sx >> 2) * K + rx) * 64 + src];
+			shv[x] = 16 * h + ((sx & 1) << 3) + ((sx & 2) << 1);
+		}
+#pragma unroll
+		for (int x = 0; x < 4; ++x) {
+			/* {bit 3: U winner, bit 2: L extended, pM[1:0]} -- the cells of the one-pass kernels.  In L: LOW 3 if it extended, else
+			 * MID 2; in M: pM; in U: MID 2 if it opened (bit 3 with scores x16, its complement with x4), else UPP 1 */
+			const uint32_t nb = nbv[x] >> shv[x];
+			const uint32_t lres = 2u + ((nb >> 2) & 1u), mres = nb & 3u, ures = TS == 4 ? 1u + ((nb >> 3) & 1u) : 2u - ((nb >> 3) & 1u);
+			nst[x] = (lres & mL) | (mres & mM) | (ures & mU);
+		}
+		/* e_x = 1 while the state stays what it was: ((a ^ b) - 1) >> 31 is a == b */
+		const uint32_t e0 = ((nst[0] ^ ust) - 1u) >> 31, e1 = e0 & (((nst[1] ^ ust) - 1u) >> 31), e2 = e1 & (((nst[2] ^ ust) - 1u) >> 31);
+		const int mdi = -di, mdj = -dj;
+		const int lim = imin(imin((rr & mdi) | (3 & ~mdi), (ss & mdj) | (3 & ~mdj)), own_len - wcnt - 1);   /* ops beyond the first that stay inside */
+		const int n = imin(1 + (int)(e0 + e1 + e2), lim + 1);
+		const uint32_t op4 = (inL | (2u & mU)) * 0x01010101u;                  /* LOW 1, MID 0, UPP 2 */
+		if (__builtin_expect(wcnt + 4 <= own_len, 1)) __builtin_memcpy(wops + wcnt, &op4, 4);   /* (bytes behind the walk's end are rewritten or never read) */
+		else {
+#pragma nounroll
+			for (int x = 0; x < n; ++x) wops[wcnt + x] = (uint8_t)op4;
+		}
+		wst = (int)(((nst[0] | (nst[1] << 4) | (nst[2] << 8) | (nst[3] << 12)) >> (4 * (n - 1))) & 15u);
+		wci -= n * di; wcj -= n * dj; wcnt += n;
+	}
 }
 
 /* A wavefront of walkers.  Half h of lane l starts with alignment 2 (wave * 64 + l) + h of the launch and, when its walk has arrived,
@@ -315,6 +415,7 @@ AT_DEV void walk16_wave(const Sweep16Args &a, const long long wave, unsigned lon
 	const int nsm = HASJ ? a.nsm : 0;
 	const int SM0 = 0, S0 = (nsm + 1) / 2 * 2, P0 = S0 + (CB + 1) * 128, PJ0 = P0 + K * S4N * 64;
 	(void)KG;
+	long long stt[3] = {0, 0, 0};
 	long long st_t0 = 0, st_t1 = 0, st_rep = 0, st_walk = 0;   /* (-DAT_TP_STATS=1: cycles of this wavefront's start-up, replays and walks) */
 	(void)st_t0; (void)st_t1; (void)st_rep; (void)st_walk;
 	if (AT_TP_STATS) st_t0 = (long long)__builtin_amdgcn_s_memtime();
@@ -368,78 +469,6 @@ AT_DEV void walk16_wave(const Sweep16Args &a, const long long wave, unsigned lon
 		if (wave * 64 + lane < nhalf[h]) take(h, wave * 64 + lane);
 	bool more[2] = {counter != nullptr, counter != nullptr};
 
-	/* one walker inside its block (bl, c): while its state does not change a walk keeps its direction (LOW up, MID diagonal, UPP /
-	 * JUMP left) and its op: the cells of the next four ops along it are read together; n of them are consumed -- up to the first
-	 * one that changes the state, the block's edge, the end of the ops slot */
-	auto walk = [&](const int h, int &wci, int &wcj, int &wst, int &wcnt, uint8_t *wops, const int bl, const int c) {
-		const int i_lo = bl * K, t_lo = imax(c << LCB, bl) - bl;   /* row (0-based) and column - 1 of the block's first cell */
-		for (;;) {
-			/* inside the block both offsets are >= 0.  st = 0: HOME, or a corrupt pointer (the round loop sorts it out), or the jump state */
-			const int rr = wci - 1 - i_lo, ss = wcj - 1 - t_lo;
-			if ((rr | ss) < 0 || wcnt >= own_len || (wst == 0 && !HASJ)) break;
-			if constexpr (HASJ) {
-				if (wst == 0) {
-					/* jump state (:579-583): left along the row until the column where J opened from M.  A plane word holds my row's
-					 * bits of 4 steps, {step 1, step 3, step 0, step 2}; up to 4 words -- 16 columns -- put in column order, the steps
-					 * behind mine shifted out: the first set bit is where J opened */
-					constexpr unsigned long long ORD = 0xfbea7362d9c85140ull;
-					const int s4 = ss >> 2, tk = ss & 3;
-					uint32_t cols = 0;
-#pragma unroll
-					for (int x = 0; x < 4; ++x) {
-						const uint32_t w = at_lds[PJ0 + (imax(s4 - x, 0) * KG + (rr >> 2)) * 64 + lane];
-						const uint32_t nib = (w >> (16 * h + cell_shift<4>(rr & 3))) & 15u;
-						cols = (cols << 4) | ((uint32_t)(ORD >> (4 * nib)) & 15u);
-					}
-					cols = (cols << (3 - tk)) & 0xffffu;                         /* bit 15 = column cj */
-					const int avail = 4 * imin(4, s4 + 1) - (3 - tk);          /* columns of this block from mine leftwards */
-					const int lim = imin(imin(avail, wcj), own_len - wcnt);
-					const int n = __clz((int)((cols << 16) | 0x8000u));
-					const int steps = n < lim ? n + 1 : lim;
-					if (n < lim) wst = 2;
-					for (int x = 0; x < steps; ++x) wops[wcnt + x] = 3;
-					wcnt += steps; wcj -= steps;
-					continue;
-				}
-			}
-			/* (the state machine without compares: written with selects hipcc makes branches of it and puts a wait between the four
-			 * reads.  st is 1, 2 or 3 here) */
-			const uint32_t ust = (uint32_t)wst;
-			const uint32_t inL = ust & (ust >> 1), inM = (ust >> 1) & ~ust & 1u;   /* st == 3, st == 2 */
-			const int di = (int)(ust >> 1), dj = (int)(inL ^ 1u);
-			const uint32_t mL = 0u - inL, mM = 0u - inM, mU = ~(mL | mM);
-			uint32_t nbv[4], nst[4];
-			int shv[4];
-#pragma unroll
-			for (int x = 0; x < 4; ++x) {
-				const int rx = imax(rr - x * di, 0), sx = imax(ss - x * dj, 0);
-				nbv[x] = at_lds[P0 + ((sx >> 2) * K + rx) * 64 + lane];
-				shv[x] = 16 * h + ((sx & 1) << 3) + ((sx & 2) << 1);
-			}
-#pragma unroll
-			for (int x = 0; x < 4; ++x) {
-				/* {bit 3: U winner, bit 2: L extended, pM[1:0]} -- the cells of the one-pass kernels.  In L: LOW 3 if it extended, else
-				 * MID 2; in M: pM; in U: MID 2 if it opened (bit 3 with scores x16, its complement with x4), else UPP 1 */
-				const uint32_t nb = nbv[x] >> shv[x];
-				const uint32_t lres = 2u + ((nb >> 2) & 1u), mres = nb & 3u, ures = TS == 4 ? 1u + ((nb >> 3) & 1u) : 2u - ((nb >> 3) & 1u);
-				nst[x] = (lres & mL) | (mres & mM) | (ures & mU);
-			}
-			/* e_x = 1 while the state stays what it was: ((a ^ b) - 1) >> 31 is a == b */
-			const uint32_t e0 = ((nst[0] ^ ust) - 1u) >> 31, e1 = e0 & (((nst[1] ^ ust) - 1u) >> 31), e2 = e1 & (((nst[2] ^ ust) - 1u) >> 31);
-			const int mdi = -di, mdj = -dj;
-			const int lim = imin(imin((rr & mdi) | (3 & ~mdi), (ss & mdj) | (3 & ~mdj)), own_len - wcnt - 1);   /* ops beyond the first that stay inside */
-			const int n = imin(1 + (int)(e0 + e1 + e2), lim + 1);
-			const uint32_t op4 = (inL | (2u & mU)) * 0x01010101u;                  /* LOW 1, MID 0, UPP 2 */
-			if (__builtin_expect(wcnt + 4 <= own_len, 1)) __builtin_memcpy(wops + wcnt, &op4, 4);   /* (bytes behind the walk's end are rewritten or never read) */
-			else {
-#pragma nounroll
-				for (int x = 0; x < n; ++x) wops[wcnt + x] = (uint8_t)op4;
-			}
-			wst = (int)(((nst[0] | (nst[1] << 4) | (nst[2] << 8) | (nst[3] << 12)) >> (4 * (n - 1))) & 15u);
-			wci -= n * di; wcj -= n * dj; wcnt += n;
-		}
-	};
-
 	int nrounds = 0;
 	if (AT_TP_STATS) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); st_t1 = (long long)__builtin_amdgcn_s_memtime(); }
 	for (;;) {
@@ -475,31 +504,135 @@ AT_DEV void walk16_wave(const Sweep16Args &a, const long long wave, unsigned lon
 		long long st_a = 0, st_b = 0;
 		(void)st_a; (void)st_b;
 		if (AT_TP_STATS) { st_a = (long long)__builtin_amdgcn_s_memtime(); ++nrounds; }
-		replay16_lane<MODE, K, TS, BITS, CB>(a, gi[0], gi[1], lane0[0], lane0[1], qq[0], qq[1], rr2[0], rr2[1], bl[0], c[0], bl[1], c[1], SM0, S0, P0, PJ0);
+		replay16_lane<MODE, K, TS, BITS, CB>(a, gi[0], gi[1], lane0[0], lane0[1], qq[0], qq[1], rr2[0], rr2[1], bl[0], c[0], bl[1], c[1], SM0, S0, P0, PJ0, stt);
 		if (AT_TP_STATS) { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); st_b = (long long)__builtin_amdgcn_s_memtime(); st_rep += st_b - st_a; }
-		if (go[0]) walk(0, ci[0], cj[0], st[0], cnt[0], ops[0], bl[0], c[0]);
-		if (go[1]) walk(1, ci[1], cj[1], st[1], cnt[1], ops[1], bl[1], c[1]);
+		if (go[0]) walk16_block<MODE, K, TS, CB>(0, lane, ci[0], cj[0], st[0], cnt[0], ops[0], own_len, bl[0], c[0], P0, PJ0);
+		if (go[1]) walk16_block<MODE, K, TS, CB>(1, lane, ci[1], cj[1], st[1], cnt[1], ops[1], own_len, bl[1], c[1], P0, PJ0);
 		if (AT_TP_STATS) st_walk += (long long)__builtin_amdgcn_s_memtime() - st_b;
 	}
 	if (AT_TP_STATS && lane == 0) {
 		/* the words behind the work counter: wavefronts, rounds, cycles (whole wavefront, start-up, replays, walks), the longest wavefront */
 		const long long now = (long long)__builtin_amdgcn_s_memtime();
 		atomicAdd(a.queue + 1, 1ull); atomicAdd(a.queue + 2, (unsigned long long)nrounds);
-		atomicAdd(a.queue + 3, (unsigned long long)(now - st_t0)); atomicAdd(a.queue + 4, (unsigned long long)(st_t1 - st_t0));
-		atomicAdd(a.queue + 5, (unsigned long long)st_rep); atomicAdd(a.queue + 6, (unsigned long long)st_walk);
-		atomicMax(a.queue + 7, (unsigned long long)(now - st_t0));
+		atomicAdd(a.queue + 3, (unsigned long long)(now - st_t0));
+		if (AT_TP_STATS == 2) {   /* the replays apart: first loads + staging, the state's set-up, the step loop; the walks */
+			atomicAdd(a.queue + 4, (unsigned long long)stt[0]); atomicAdd(a.queue + 5, (unsigned long long)stt[1]);
+			atomicAdd(a.queue + 6, (unsigned long long)stt[2]); atomicAdd(a.queue + 7, (unsigned long long)st_walk);
+		} else {
+			atomicAdd(a.queue + 4, (unsigned long long)(st_t1 - st_t0));
+			atomicAdd(a.queue + 5, (unsigned long long)st_rep); atomicAdd(a.queue + 6, (unsigned long long)st_walk);
+			atomicMax(a.queue + 7, (unsigned long long)(now - st_t0));
+		}
+	}
+}
+
+/* A wavefront of walker TEAMS (the 64-lane groups: alignments whose walks cross a hundred blocks).  NT lanes share the two alignments of
+ * one work item of the sweep: a round replays NT blocks per alignment -- those its walk is heading for, CkPattern's exact per-band lists
+ * seen from the walker's cell, as in the rounds inside the sweep's kernel -- and the walkers (team lane 0: the even alignment's, lane 1:
+ * the odd one's) walk from block to block through the columns of LDS their team-mates filled, until they stand in a block the round
+ * has not replayed.  A chain of ~100 dependent rounds per alignment becomes one of ~35: C3's walk kernel 3.3 -> ~1 ms. */
+template <int MODE, int G, int K, int TS, int BITS, int CB, int NT>
+AT_DEV void walk16_team_wave(const Sweep16Args &a, const long long wave)
+{
+	constexpr bool HASJ = MODE == K_FITJ;
+	constexpr bool ISFIT = MODE == K_FIT || MODE == K_FITJ;
+	constexpr int NG = 64 / G, LCB = ck_log2(CB), KG = (K + 3) / 4, S4N = CB / 4, TPW = 64 / NT;
+	static_assert(NT >= 2 && NT <= 32 && 64 % NT == 0, "team width");
+	const int lane = threadIdx.x, tl = lane % NT, t0 = lane - tl;      /* my place in my team, my team's lane 0 */
+	const int nsm = HASJ ? a.nsm : 0;
+	const int SM0 = 0, S0 = (nsm + 1) / 2 * 2, P0 = S0 + (CB + 1) * 128, PJ0 = P0 + K * S4N * 64;
+	(void)KG; (void)LCB;
+	if constexpr (HASJ) {
+		for (int w = lane; w < nsm; w += 64) at_lds[SM0 + w] = a.sitemask[w];
+		__builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+	}
+	const int own_len = a.l1 + a.l2;
+	constexpr int BLKS = G <= 16 ? 4 : 8;
+	const int ck_T = (a.l2 + G - 1 + BLKS - 1) / BLKS * BLKS;          /* steps of the sweep (sweep16_items) */
+	/* my team's pair of alignments: 2 u (even, low halves) and 2 u + 1 (odd, high halves) */
+	const long long u = wave * TPW + lane / NT;
+	const long long npair2 = (a.npairs + 1) / 2;
+	const bool team = u < npair2;
+	const long long pA = team ? 2 * u : 0, pB = team && 2 * u + 1 < a.npairs ? 2 * u + 1 : pA;
+	const long long wk = pA / (2 * NG);
+	const int lane0 = (int)((pA - wk * (2 * NG)) >> 1) * G;
+	const uint32_t *gi = a.ck + wk * a.ck_item_words;
+	const uint32_t *qA = a.seq + a.woff1[pA], *qB = a.seq + a.woff1[pB], *rA = a.seq + a.woff2[pA], *rB = a.seq + a.woff2[pB];
+	/* the walker I am, if any: team lane 0 walks the even alignment (h = 0), team lane 1 the odd one (h = 1) */
+	const int h = tl & 1;
+	const long long pw = h ? 2 * u + 1 : 2 * u;
+	const bool walker = team && tl < 2 && pw < a.npairs;
+	int ci = 0, cj = 0, st = 2, cnt = 0, myrounds = 0;
+	bool ok = false, ok0 = false;
+	uint8_t *ops = a.ops;
+	if (walker) {
+		const int4 e = a.tp_end[pw];
+		ci = e.x; cj = e.y; st = e.z; ok = e.w != 0; ok0 = ok;
+		ops = a.ops + a.ops_off[pw];
+	}
+	for (;;) {
+		/* has my walk arrived?  local: HOME (:788-791) or a border; global: a border (then the padding loops); fit: row 0 */
+		bool fin = !walker || !ok || ci <= 0 || (!ISFIT && cj <= 0) || (MODE == K_LOCAL && st == 0);
+		if (!fin && (cj <= 0 || cnt >= own_len || (st == 0 && !HASJ) || myrounds > own_len + 8)) { ok = false; fin = true; }
+		const bool go = !fin;
+		if (!__any(go)) break;
+		++myrounds;
+		/* a walk in U (1) or the jump state (0, fit -s only) runs left along its row; in M or L it climbs */
+		CkPattern<NT, K, CB> pat;
+		pat.set(go ? ci : 1, go ? cj : 1, st == 1 || (HASJ && st == 0));
+		/* the anchors of my team's two walkers -> my two blocks */
+		int bl[2], c[2];
+#pragma unroll
+		for (int hh = 0; hh < 2; ++hh) {
+			CkPattern<NT, K, CB> q;
+			q.b = __shfl(pat.b, t0 + hh); q.c0 = __shfl(pat.c0, t0 + hh);
+			q.thi1 = __shfl(pat.thi1, t0 + hh); q.horiz = __shfl(pat.horiz, t0 + hh);
+			const int alive = __shfl(go ? 1 : 0, t0 + hh);
+			bool v;
+			q.block(tl, ck_T, bl[hh], c[hh], v);
+			if (!v || !alive) { bl[hh] = 0; c[hh] = 0; }      /* (a slot nobody reads: the first block of band 0) */
+		}
+		replay16_lane<MODE, K, TS, BITS, CB>(a, gi, gi, lane0, lane0, qA, qB, rA, rB, bl[0], c[0], bl[1], c[1], SM0, S0, P0, PJ0);
+		__builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");      /* my team-mates' columns of LDS */
+		if (go) {
+			for (;;) {
+				if (ci <= 0 || cj <= 0 || cnt >= own_len || (st == 0 && (!HASJ || MODE == K_LOCAL))) break;
+				const int wb = (ci - 1) / K, wc = ((cj - 1) + wb) >> LCB;
+				const int q = pat.slot(wb, wc);
+				if (q < 0) break;                                  /* (outside this round's blocks: the next round starts here) */
+				const int before = cnt, bi = ci, bj = cj, bs = st;
+				walk16_block<MODE, K, TS, CB>(h, t0 + q, ci, cj, st, cnt, ops, own_len, wb, wc, P0, PJ0);
+				if (cnt == before && ci == bi && cj == bj && st == bs) break;   /* (nothing moved: the round loop sorts it out) */
+			}
+		}
+		__builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");      /* (the walks have read this round's words before the next replay writes) */
+	}
+	if (walker) {
+		if constexpr (MODE == K_GLOBAL) {                             /* padding loops :398-407 */
+			if (ok) {
+				while (cj > 0 && cnt < own_len) { ops[cnt++] = 2; --cj; }
+				while (ci > 0 && cnt < own_len) { ops[cnt++] = 1; --ci; }
+				if (ci > 0 || cj > 0) ok = false;
+			}
+		}
+		if (ok0 && !ok) a.score[pw] = INT32_MIN;
+		a.nops[pw] = ok ? cnt : -1;
 	}
 }
 
 /* The kernel.  `a`: the launch's main work items; `t`: its sliver (the items of two 32-lane groups that end a launch of narrow-group
  * items, at_sweep16): their walks take the first wavefronts of the same launch -- a launch of their own was a second chain of cold
  * instruction fetches and round trips behind the first (C2: 0.2 ms for 2 % of the alignments).  G2 = 0: no sliver. */
-template <int MODE, int G, int K, int TS, int BITS, int CB, int G2 = 0, int K2 = 0>
+template <int MODE, int G, int K, int TS, int BITS, int CB, int G2 = 0, int K2 = 0, int NT = 1>
 __global__ __launch_bounds__(64, 2) void at_walk16(const Sweep16Args a, const Sweep16Args t)
 {
 	if (a.only_if && __builtin_amdgcn_readfirstlane(*a.only_if) != a.only_val) return;
 	/* a few wavefronts, each a long chain of dependent steps, beside the sweeps of the launches around them: they go first at the issue */
 	if (AT_WALK_KPRIO) __builtin_amdgcn_s_setprio(AT_WALK_KPRIO);
+	if constexpr (NT > 1) {   /* teams of NT lanes per pair of alignments: one wavefront per 64 / NT pairs */
+		walk16_team_wave<MODE, G, K, TS, BITS, CB, NT>(a, blockIdx.x);
+		return;
+	}
 	long long wave = blockIdx.x, nmain = gridDim.x;
 	if constexpr (G2 > 0) {
 		const long long nt = (t.npairs + 127) / 128;

@@ -639,7 +639,8 @@ def main():
             "roofline": dict(valu or {"bound": "valu", "achieved": None, "peak": None, "unit": "G wave-instr/s", "frac": None,
                                       "note": "no SQ_INSTS_VALU profile for this kernel configuration under profiles/%s" % PROFILE_ROUND},
                              traffic=traffic,
-                             kernel=("at_sweep16" if "packed16" in al.last_config else "at_myers" if "myers" in al.last_config else "at_sweep") + "<%s>" % mode,
+                             kernel=("at_sweep16" if "packed16" in al.last_config else "at_myers" if "myers" in al.last_config else "at_sweep") + "<%s>" % mode +
+                                    (" + at_walk16" if "walk kernel" in al.last_config else ""),
                              kernel_avg_ms=kern_avg_ms, kernel_min_ms=kern_ms[0], kernel_alone_ms=kern_iso_ms, launches_in_flight=S,
                              host_issue_ms_per_step=(t_issued - t0) * 1e3 / max(1, args.steps),
                              gcups_one_launch_at_a_time=cells_per_step / world / (kern_iso_ms * 1e-3) / 1e9,

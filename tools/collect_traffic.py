@@ -107,6 +107,21 @@ def main():
                 res["hbm_bytes_per_launch"] = int(round(2 * g("FETCH_SIZE") * 1024 + g("WRITE_SIZE") * 1024))
                 res["note"] = "FETCH_SIZE doubled per MI355X_MICROARCH.md (gfx950 tallies 128-byte read requests at 64 bytes); WRITE_SIZE as read"
             res["sq_counters_per_launch"] = {c: s[c]["mean"] for c in s if c.startswith("SQ_") or c.startswith("GRBM")}
+            # two-pass tracebacks with pass 2 as a kernel of its own (at_walk16): a step is the sweep AND its walk kernel -- their counters added
+            walks = {k: v for k, v in res["kernels"].items() if "at_walk16" in k}
+            if walks:
+                wname = max(walks, key=lambda k: walks[k].get("SQ_INSTS_VALU", {}).get("mean", 0.0))
+                wk = walks[wname]
+                res["walk_kernel"] = wname
+                res["per_kernel"] = {"sweep": {"hbm_bytes": res.get("hbm_bytes_per_launch"), "SQ_INSTS_VALU": g("SQ_INSTS_VALU")},
+                                     "walk": {"SQ_INSTS_VALU": wk.get("SQ_INSTS_VALU", {}).get("mean")}}
+                if "FETCH_SIZE" in wk and "WRITE_SIZE" in wk and "hbm_bytes_per_launch" in res:
+                    wb = int(round(2 * wk["FETCH_SIZE"]["mean"] * 1024 + wk["WRITE_SIZE"]["mean"] * 1024))
+                    res["per_kernel"]["walk"]["hbm_bytes"] = wb
+                    res["hbm_bytes_per_launch"] += wb
+                for c in list(res["sq_counters_per_launch"]):
+                    if c in wk:
+                        res["sq_counters_per_launch"][c] += wk[c]["mean"]
         # the counters belong to this state of the kernels: bench.py checks the fingerprint before it prices a roofline with them
         sys.path.insert(0, ROOT)
         from aligntools.c_amd import kernel_source_sha16

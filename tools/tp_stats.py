@@ -51,8 +51,13 @@ for w in sys.argv[1:] or ["C2", "C3", "C4"]:
     print("%s: %.3f ms  %s" % (w, e0.elapsed_time(e1), al.last_config[:110]))
     if "walk kernel" in al.last_config:
         wv = max(1, d[1])
-        print("   walk kernel: wavefronts %d  rounds/wavefront %.2f  kcycles/wavefront %.0f (start-up %.0f, replays %.0f, walks %.0f), longest %.0f"
-              % (d[1], d[2] / wv, d[3] / wv / 1e3, d[4] / wv / 1e3, d[5] / wv / 1e3, d[6] / wv / 1e3, int(out[7]) / 1e3))
+        if os.environ.get("TP_STATS_LEVEL") == "2":   # a -DAT_TP_STATS=2 build: the replays apart
+            rd = max(1, d[2])
+            print("   walk kernel: wavefronts %d  rounds/wavefront %.2f  kcycles/wavefront %.0f; per round: first loads + staging %.1f, set-up %.1f, step loop %.1f, walks %.1f"
+                  % (d[1], d[2] / wv, d[3] / wv / 1e3, d[4] / rd / 1e3, d[5] / rd / 1e3, d[6] / rd / 1e3, d[7] / rd / 1e3))
+        else:
+            print("   walk kernel: wavefronts %d  rounds/wavefront %.2f  kcycles/wavefront %.0f (start-up %.0f, replays %.0f, walks %.0f), longest %.0f"
+                  % (d[1], d[2] / wv, d[3] / wv / 1e3, d[4] / wv / 1e3, d[5] / wv / 1e3, d[6] / wv / 1e3, int(out[7]) / 1e3))
         al.close()
         continue
     print("   items %d  rounds/item %.2f  kcycles/item: forward %.0f  pass 2 %.0f (replay %.0f, walks %.0f of which block copies %.0f)"

@@ -546,7 +546,7 @@ static TpLayout tp_layout(const Layout16 &L, int kmode, int l2, bool split = fal
 {
 	const int blk = L.g <= 16 ? 4 : 8, cb = at::ck_steps(L.g);
 	const long long T = (long long)((l2 + L.g - 1 + blk - 1) / blk) * blk;   /* steps of a sweep */
-	const int es = kmode == at::K_FITJ ? 4 : 3, nq = ((kmode == at::K_FITJ ? 3 : 2) * L.k + 3) / 4, kg = (L.k + 3) / 4;
+	const int es = 2, nq = ((kmode == at::K_FITJ ? 3 : 2) * L.k + 3) / 4, kg = (L.k + 3) / 4;
 	auto up4 = [](long long v) { return (v + 3) & ~3LL; };
 	TpLayout t;
 	long long w = 0;

@@ -250,7 +250,8 @@ AT_DEV int pidx(int wr, int r, int lane, int NL)
  *
  * What it buys (one MI355X, profiles/r04/two_pass_ab.jsonl): the 64-lane group with 16 rows per lane -- reads of 609 .. 1 024
  * bases, where the one-pass kernels hold 4 rows per lane in four strips -- C3 2 940 -> 3 170 GCUPS with launches in flight,
- * 2 110 -> 2 860 one launch at a time: the default there.  The 8-lane groups x 19 rows lose (C2 3 050 -> 2 850, C4 2 200 ->
+ * 2 110 -> 2 860 one launch at a time.  (Since pass 2 exists as a kernel of its own -- at_walk16.hip.h, teams of walker lanes: 4 050 /
+ * 3 160 -- that form is the default there and the rounds below are what AT_TP_SPLIT=0 and a failed allocation fall back to.)  The 8-lane groups x 19 rows lose (C2 3 050 -> 2 850, C4 2 200 ->
  * 1 580: a round replays 19 x 16 cells in every lane for the dozen cells a short walk needs, and long walks need ten rounds)
  * and stay on the one-pass kernels unless AT_TWO_PASS=2 asks.
  * ====================================================================================================================== */
@@ -274,7 +275,7 @@ AT_DEV int pidx(int wr, int r, int lane, int NL)
 #define AT_CK_W64 3       /* t-blocks per band of a round on the 64-lane group */
 #endif
 constexpr int ck_steps(int g) { return g == 64 ? AT_CK_STEPS64 : AT_CK_STEPS; }
-template <int MODE> constexpr int ck_es() { return MODE == K_FITJ ? 4 : 3; }                     /* words of a row checkpoint entry */
+template <int MODE> constexpr int ck_es() { return 2; }                                          /* words of a row checkpoint entry (ck_entry) */
 template <int MODE, int K> constexpr int ck_nq() { return ((MODE == K_FITJ ? 3 : 2) * K + 3) / 4; }   /* 16-byte chunks of a column checkpoint */
 constexpr int ck_log2(int v) { return v <= 1 ? 0 : 1 + ck_log2(v / 2); }
 /* Where the checkpoints lie (words from off_rck / off_cck).  The sweep produces them step by step, 64 lanes at a time; a replay (the walk
@@ -399,6 +400,19 @@ AT_DEV uint32_t lohi(uint32_t lo, uint32_t hi)   /* low half of `lo`, high half 
 	return __builtin_amdgcn_perm(hi, lo, 0x07060100u);
 }
 struct ck_u3 { uint32_t x, y, z; };
+/* A row checkpoint entry: (L, M, U[, J]) of a lane's last row AS THE LANE BELOW SEES THEM -- X' = max(L, M, U[, J]) with the winner's
+ * priority tag (the diagonal input of its first row) and L of the row below = max(L + e, M + o) (tagged: extended or opened) -- 8 bytes
+ * for the two alignments of a lane where (L, M, U[, J]) were 12 / 16.  The sweep is the scores-only sweep (no tags): it ORs them in
+ * here, nine instructions per step.  (C3's sweep writes 5.6 GB of checkpoints per launch at 2.9 TB/s -- that, not its instructions, is
+ * what bounds it once pass 2 is out of the way: DESIGN.md 3.6.1.) */
+template <bool HASJ>
+AT_DEV uint2 ck_entry(uint32_t eL, uint32_t eM, uint32_t eU, uint32_t eJ, uint32_t e2, uint32_t o2, uint32_t tagL, uint32_t tagM, uint32_t tagU)
+{
+	const uint32_t tl = eL | tagL, tm = eM | tagM;
+	uint32_t xx = pmax(pmax(tl, tm), eU | tagU);
+	if constexpr (HASJ) xx = pmax(xx, eJ);
+	return make_uint2(xx, pmax(padd(tl, e2), padd(tm, o2)));
+}
 
 /* One round's replay: this lane's two blocks -- (blA, cA) of the alignment in the low halves, (blB, cB) of the one in the
  * high halves; band = lane-in-group of the forward sweep, c = t-block -- swept with tags from their checkpoints, pointer
@@ -455,17 +469,12 @@ AT_REPLAY_FN void replay16_block(const Sweep16Args &a, const Slot<SMALL> &mem, u
 	 *      exist (registers are free now) and cost one round trip; the step loop then reads two words per step from LDS. ---- */
 	const int stg = a.off_bound + lane * 2;
 	{
-		typedef typename std::conditional<ES == 4, uint4, ck_u3>::type ent_t;
-		ent_t ra[CB + 1], rb[CB + 1];
+		static_assert(ES == 2, "row checkpoint entries: (X', L of the row below), ck_entry");
+		uint2 ra[CB + 1], rb[CB + 1];
 #pragma unroll
-		for (int x = 0; x <= CB; ++x) { ra[x] = *(const ent_t *)(gs + entA(x)); rb[x] = *(const ent_t *)(gs + entB(x)); }
+		for (int x = 0; x <= CB; ++x) { ra[x] = *(const uint2 *)(gs + entA(x)); rb[x] = *(const uint2 *)(gs + entB(x)); }
 #pragma unroll
-		for (int x = 0; x <= CB; ++x) {
-			const uint32_t eL = lohi(ra[x].x, rb[x].x), eM = lohi(ra[x].y, rb[x].y), eU = lohi(ra[x].z, rb[x].z);
-			uint32_t xx = pmax(pmax(eL | cTagL, eM | cTagM), eU | cTagU);
-			if constexpr (ES == 4) xx = pmax(xx, lohi(ra[x].w, rb[x].w));
-			mem.st2(stg + x * 128, xx, pmax(padd(eL | cTagL, e2), padd(eM | cTagM, o2)));
-		}
+		for (int x = 0; x <= CB; ++x) mem.st2(stg + x * 128, lohi(ra[x].x, rb[x].x), lohi(ra[x].y, rb[x].y));
 	}
 
 	uint32_t Mo_l[K], U_l[K], Xl[2][K], J_l[HASJ ? K : 1], qsel[K], acc[K];
@@ -713,6 +722,10 @@ AT_DEV long long sweep16_items(const Sweep16Args &a, long long wnext, const long
 	uint32_t cM3 = 0x00030003u, cM7 = 0x00070007u, cNib = 0x000f000fu, cF0 = 0x00f000f0u, cF000 = 0xf000f000u;
 	uint32_t c8888 = 0x88888888u, c3333 = 0x33333333u;
 	asm volatile("" : "+v"(c8888), "+v"(c3333));
+	/* two-pass: the tags the replay's arithmetic carries, for the row checkpoint entries (ck_entry) of a sweep that runs without them */
+	uint32_t cRTagL = (uint32_t)OTGL * 0x00010001u, cRTagM = (uint32_t)OTGM * 0x00010001u, cRTagU = (uint32_t)OTGU * 0x00010001u;
+	(void)cRTagL; (void)cRTagM; (void)cRTagU;
+	if constexpr (CK > 0) asm volatile("" : "+v"(cRTagL), "+v"(cRTagM), "+v"(cRTagU));
 	/* jump state: J(i,j) = max(M(i,j-1) + g, J(i,j-1)) where the column may open, else J(i,j-1) (alignment.h:658-666);
 	 * the left state holds M + o, so the opening candidate is (M + o) + (g - o), or -inf where opening is barred */
 	uint32_t gmo2 = pk2(a.g16 - a.o16), neg2 = 0x80008000u;
@@ -739,8 +752,8 @@ AT_DEV long long sweep16_items(const Sweep16Args &a, long long wnext, const long
 		for (int j = lane; j <= l2; j += 64) {
 			int L, M, U;
 			border16<MODE>(0, j, o16, e16, L, M, U);
-			brow[j * ES] = pk2(sat16(L)); brow[j * ES + 1] = pk2(M); brow[j * ES + 2] = pk2(U);
-			if constexpr (ES == 4) brow[j * ES + 3] = 0x80008000u;
+			const uint2 en = ck_entry<HASJ>(pk2(sat16(L)), pk2(M), pk2(U), 0x80008000u, e2, o2, cRTagL, cRTagM, cRTagU);
+			brow[j * ES] = en.x; brow[j * ES + 1] = en.y;
 		}
 	}
 
@@ -901,8 +914,8 @@ AT_DEV long long sweep16_items(const Sweep16Args &a, long long wnext, const long
 				border16<MODE>(i0 + K, 0, o16, e16, L, M, U);
 				ckL = pk2(sat16(L)); ckM = pk2(M); ckU = pk2(U);
 				const int p0 = a.off_rck + ck_rck_word<ES>(0, lane);
-				gs[p0] = ckL; gs[p0 + 1] = ckM; gs[p0 + 2] = ckU;
-				if constexpr (ES == 4) gs[p0 + 3] = ckJ;
+				const uint2 en = ck_entry<HASJ>(ckL, ckM, ckU, ckJ, e2, o2, cRTagL, cRTagM, cRTagU);
+				gs[p0] = en.x; gs[p0 + 1] = en.y;
 			}
 			uint32_t A_prev = Xl[0][K - 1], B_prev = 0, Ad;
 			{
@@ -1166,8 +1179,7 @@ AT_DEV long long sweep16_items(const Sweep16Args &a, long long wnext, const long
 						static_assert(!TP || AT_CK_ROW_TILE <= 1 || BLK % AT_CK_ROW_TILE == 0, "a tile of row checkpoints lies in one block of steps");
 						constexpr int RT = AT_CK_ROW_TILE > 1 ? AT_CK_ROW_TILE : 1;
 						constexpr int so = (k / RT) * 64 * RT * ES + (k % RT) * ck_rck_step<ES>();   /* (t0 is a multiple of the tile: step k lies k / RT tiles on) */
-						if constexpr (ES == 4) *(uint4 *)(gs + ck_p + so) = make_uint4(ckL, ckM, ckU, ckJ);
-						else { gs[ck_p + so] = ckL; gs[ck_p + so + 1] = ckM; gs[ck_p + so + 2] = ckU; }
+						*(uint2 *)(gs + ck_p + so) = ck_entry<HASJ>(ckL, ckM, ckU, ckJ, e2, o2, cRTagL, cRTagM, cRTagU);
 					}
 					if constexpr (TB) {
 						if constexpr (OVL && PB == 2) {

@@ -15,9 +15,15 @@
  * the exact boundary values, so the ops are those of the one-pass kernels (trace_back_gla / _local_affine /
  * _fit_affine_jump, alignment.h:372-412, 558-592, 766-800).
  *
- * The two alignments of a lane are the two of one group of one work item of the sweep (alignment 2g in the low halves of
- * its checkpoint words, 2g + 1 in the high halves), so a lane reads one item's region and `lohi` puts the halves together
- * exactly as the sweep had them.
+ * The even alignment of a group of the sweep lives in the low halves of its checkpoint words, the odd one in the high
+ * halves: half 0 of a lane walks even alignments, half 1 odd ones, and `lohi` joins two unrelated blocks exactly as the
+ * sweep packed them.
+ *
+ * Two forms.  walk16_wave (the 8-lane groups; AT_TP_SPLIT=1): every half-lane a walker of its own, persistent wavefronts
+ * that refill finished halves from two counters.  walk16_team_wave (the 64-lane groups, where a walk crosses a hundred
+ * blocks; the default there): teams of NT lanes share one pair of alignments, a round replays the NT blocks per alignment
+ * the walk is heading for, and the chain of dependent rounds per alignment is a third as long (C3: 2 900 -> 4 050 GCUPS with
+ * launches in flight, 2 660 -> 3 160 one at a time, against the rounds inside the sweep's kernel).  DESIGN.md 3.6.1.
  */
 #pragma once
 #include "at_sweep16.hip.h"
@@ -88,17 +94,15 @@ AT_DEV void replay16_lane(const Sweep16Args &a, const uint32_t *giA, const uint3
 	const int stg = S0 + lane * 2;
 	constexpr int PH = K > 16 ? 4 : 8;   /* (19 rows per lane: the registers hold a phase of 4 steps) */
 	static_assert(CB % PH == 0 && PH % 4 == 0, "phases of whole pointer words");
-	typedef typename std::conditional<ES == 4, uint4, ck_u3>::type ent_t;
+	static_assert(ES == 2, "row checkpoint entries: (X', L of the row below), ck_entry");
+	typedef uint2 ent_t;
 	ent_t ra[PH], rb[PH];
 	auto ask = [&](const int x0) {       /* entries x0 .. x0 + PH - 1 */
 #pragma unroll
 		for (int x = 0; x < PH; ++x) { ra[x] = *(const ent_t *)entA(x0 + x); rb[x] = *(const ent_t *)entB(x0 + x); }
 	};
 	auto stage1 = [&](const ent_t &va, const ent_t &vb, const int x) {
-		const uint32_t eL = lohi(va.x, vb.x), eM = lohi(va.y, vb.y), eU = lohi(va.z, vb.z);
-		uint32_t xx = pmax(pmax(eL | cTagL, eM | cTagM), eU | cTagU);
-		if constexpr (ES == 4) xx = pmax(xx, lohi(va.w, vb.w));
-		*reinterpret_cast<uint2 *>(&at_lds[stg + x * 128]) = make_uint2(xx, pmax(padd(eL | cTagL, e2), padd(eM | cTagM, o2)));
+		*reinterpret_cast<uint2 *>(&at_lds[stg + x * 128]) = make_uint2(lohi(va.x, vb.x), lohi(va.y, vb.y));
 	};
 	auto stage = [&](const int x0) {
 #pragma unroll

@@ -1623,15 +1623,16 @@ def test_two_pass_walk_kernel_batches(al, case, monkeypatch):
 
 def test_two_pass_default_routing(al, monkeypatch):
     """By default the two-pass kernels take the shapes on which they win (one strip of 64 lanes x 16 rows: reads of 609 .. 1 024
-    bases) and leave the others to the one-pass kernels."""
+    bases; pass 2 there is the walk kernel with teams of lanes) and leave the others to the one-pass kernels."""
     rng = random.Random(5)
     monkeypatch.delenv("AT_TWO_PASS", raising=False)
+    monkeypatch.delenv("AT_TP_SPLIT", raising=False)
     monkeypatch.setenv("AT_HOST_CHUNKS", "1")
     al.set_scoring(1, -1, -4, -1, -10, False, [])
     for l1, want in ((1024, True), (609, True), (150, False), (1025, False)):
         pairs = [("".join(rng.choice("ACGT") for _ in range(l1)), "".join(rng.choice("ACGT") for _ in range(l1 + 20))) for _ in range(40)]
         al.align_batch("global", pairs, traceback=True, render=False)
-        assert ("two-pass" in al.last_config) == want, (l1, al.last_config)
+        assert ("two-pass" in al.last_config) == want and ("walk kernel" in al.last_config) == want, (l1, al.last_config)
         al.align_batch("global", pairs, traceback=False, render=False)
         assert "two-pass" not in al.last_config
 

@@ -425,6 +425,12 @@ struct Layout16 {
  * lanes (8 alignments per wave, 85 %; one group of 64 lanes: 59 %) and so do 209..304 bases with 16 / 19 rows per lane,
  * 305..608 bases as 2 groups of 32 lanes (10 .. 19 rows per lane), everything
  * else as one group of 64 lanes.  AT_GROUP = 8 / 16 / 32 / 64 caps the choice (A/B runs); ragged frames name their group width themselves. */
+/* The 8-lane groups x 19 rows (reads of 129 .. 152 bases): which batches take the two-pass kernels with the walk kernel by default --
+ * fit (with or without -s) against a second sequence at least twice as long: the sweep is long against the walkers' chain of rounds
+ * (same box, launches in flight / one at a time: C4 150 x 500 -s 2 210 -> 2 380 / 1 960 -> 2 180 GCUPS, the same without -s 3 150 -> 3 750 /
+ * 2 590 -> 3 350).  Global and local 150 x 150 gain with launches in flight (2 470 -> 2 700, 3 050 -> 3 180) and lose alone (2 380 ->
+ * 2 230, 2 800 -> 2 490): AT_TWO_PASS=2 AT_TP_SPLIT=1 asks for them. */
+static bool tp_split_narrow_default(int kmode, int l1, int l2) { return (kmode == at::K_FITJ || kmode == at::K_FIT) && l2 >= 2 * l1; }
 static Layout16 layout16_for(bool tb, bool hasj, int l1, int l2, int ts, int force_g = 0, bool overlap = false, int kmode = -1, int force_k = 0, int two_pass = 0)   /* two_pass: 1 = the rounds inside the sweep's kernel (its staging area and walkers' tiles in LDS), 2 = a walk kernel; force_g: 8 / 16 = ragged frames on that group width; 64 = the 64-lane items behind a batch of narrow-group items, force_k rows per lane */
 {
 	Layout16 L;
@@ -904,14 +910,17 @@ static int align_device(at_handle *h, int mode, int64_t npairs,
 	const long long tp_mode = env_ll("AT_TWO_PASS", 1);
 	if (ts && tb && !rag && kmode <= at::K_FITJ && tp_mode) {
 		Layout16 P2 = layout16_for(false, kmode == at::K_FITJ, max_len1, max_len2, ts, 0, false, kmode, 0, 1);
-		if ((P2.g == 64 || tp_mode >= 2) && (long long)P2.g * P2.k >= max_len1 && at_pick16_tp(kmode, P2.g, P2.k, ts, bits) &&
+		/* pass 2 as a kernel of its own (at_walk16.hip.h): the sweep leaves its checkpoints per work item, walkers replay the blocks their
+		 * walks cross.  By default on the 64-lane groups, where teams of walker lanes cut the chain of rounds (C3 2 940 -> 4 420 GCUPS with
+		 * launches in flight, 2 150 -> 3 310 one at a time, against the one-pass kernels), and on the 8-lane groups for fit against a long
+		 * second sequence (tp_split_narrow_default); AT_TP_SPLIT=1: wherever a walk kernel exists, 0: nowhere (the rounds inside the sweep's kernel) */
+		const bool narrow_default = P2.g == 8 && tp_split_narrow_default(kmode, max_len1, max_len2);
+		const bool split_default = P2.g == 64 || narrow_default;
+		const int split_req = env_ll("AT_TP_SPLIT", split_default ? 1 : 0) && !h->ck_alloc_failed && at_pick_walk16(kmode, P2.g, P2.k, ts, bits) ? 1 : 0;
+		if ((P2.g == 64 || tp_mode >= 2 || (split_req && narrow_default)) && (long long)P2.g * P2.k >= max_len1 && at_pick16_tp(kmode, P2.g, P2.k, ts, bits) &&
 		    choose_store(P2.off_ptr, 1, true) == 1) {
 			two_pass = true;
-			/* pass 2 as a kernel of its own (at_walk16.hip.h): the sweep leaves its checkpoints per work item, one walker per half-lane
-			 * replays the blocks its walk crosses.  AT_TP_SPLIT=0: the rounds inside the sweep's kernel */
-			/* by default on the 64-lane groups, where teams of walker lanes cut the chain of rounds (C3 2 900 -> 3 900 GCUPS with launches
-			 * in flight, 2 660 -> 3 150 one at a time); AT_TP_SPLIT=1: wherever a walk kernel exists, 0: nowhere */
-			tp_split = env_ll("AT_TP_SPLIT", P2.g == 64 ? 1 : 0) && !h->ck_alloc_failed && at_pick_walk16(kmode, P2.g, P2.k, ts, bits) ? 1 : 0;
+			tp_split = split_req;
 			if (tp_split) P2 = layout16_for(false, kmode == at::K_FITJ, max_len1, max_len2, ts, 0, false, kmode, 0, 2);
 			P = P2;
 		}
@@ -936,6 +945,8 @@ static int align_device(at_handle *h, int mode, int64_t npairs,
 			const long long items = (cap - tail_reserve - brow_words * 4) / (tpm.words * 4 + 16LL * per_wave);
 			if (items < 1) return fail(h, AT_ERR_NOMEM, "two-pass tracebacks: one work item's checkpoints (%lld bytes) exceed AT_CK_CAP_MB", tpm.words * 4);
 			piece = std::min<int64_t>(npairs, items * per_wave);
+			const long long forced = env_ll("AT_CK_PIECE_PAIRS", 0);   /* (tests: pieces of this many pairs, whatever the cap) */
+			if (forced > 0) piece = std::min<int64_t>(piece, std::max<long long>(1, forced / per_wave) * per_wave);
 		}
 		auto walk_lane_words = [&](const Layout16 &L) -> long long {   /* a walker lane's pointer words of one block (at_walk16.hip.h) */
 			const int cb = at::ck_steps(L.g);
@@ -1058,9 +1069,12 @@ static int align_device(at_handle *h, int mode, int64_t npairs,
 			if (!wf) return fail(h, AT_ERR_RANGE, "no walk kernel for %d-lane groups x %d rows", P.g, P.k);
 			const size_t lds = std::max(walk_lds(P, true), tail_ok ? walk_lds(PT, true) : 0);
 			if (lds > 48 * 1024) HIP_TRY(h, hipFuncSetAttribute((const void *)wf, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-			/* the main units' walkers: persistent wavefronts, AT_WALK_WAVES_PER_CU (1) per CU at most, that refill their lanes from a counter
-			 * (the word behind the sweep's work counter); the sliver's: one wavefront per 128 alignments */
-			const long long wmain = std::max<long long>(1, std::min<long long>((nm + 127) / 128, env_ll("AT_WALK_WAVES_PER_CU", 1) * h->ncu));
+			/* the main units' walkers: one wavefront per 128 alignments (LDS admits four per CU; the others queue).  AT_WALK_WAVES_PER_CU = n:
+			 * at most n per CU, persistent, which refill their halves from the counters behind the sweep's work counter -- fewer
+			 * wavefront-rounds, but a chain of them per wavefront: C4 one launch at a time 1 450 (n = 1) / 1 820 (2) / 2 160 GCUPS (all),
+			 * C2 2 300 / 2 490 / 2 500, with launches in flight 2 270 / 2 370 / 2 390 and 3 130 / 3 130 / 3 140 */
+			const long long wcap = env_ll("AT_WALK_WAVES_PER_CU", 0);
+			const long long wmain = std::max<long long>(1, wcap > 0 ? std::min<long long>((nm + 127) / 128, wcap * h->ncu) : (nm + 127) / 128);
 			HIP_TRY(h, hipMemsetAsync(h->d_queue + 8, 0, 16, stream));
 			const long long wteams = ((nm + 1) / 2 + 64 / at_walk16_team_lanes() - 1) / (64 / at_walk16_team_lanes());
 			hipLaunchKernelGGL(wf, dim3((unsigned)(teams ? wteams : wmain + (n_tail + 127) / 128)), dim3(64), lds, stream, b, bt);

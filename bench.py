@@ -137,6 +137,9 @@ WORKLOADS = {
     "C3": ("global", 1024, 1024, 10000, (1, -1, -4, -1, -10), False, [], 0x5EED0003),
     "C4": ("fit", 150, 500, 100000, (2, -2, -5, -1, -10), True, [100, 200, 300, 400], 0x5EED0004),
     "C5": ("overlap", 1000, 1000, 10000, (1, -2, -5, -1, -10), False, [], 0x5EED0005),
+    # diagnostics: C2's shape under global (walks that cross the whole read), C4's without the jump state
+    "G150": ("global", 150, 150, 100000, (2, -2, -5, -2, -10), False, [], 0x5EED0012),
+    "F500": ("fit", 150, 500, 100000, (2, -2, -5, -1, -10), False, [], 0x5EED0014),
     # all-vs-all over 50k reads of 1 kbp (1.25e9 ordered pairs in full): each step scores a 100k-pair slice of the
     # triangle per GPU, pairs enumerated on the GPU (at_align_allpairs_device), scores + end cells only
     "C5all": ("overlap", 1000, 1000, 100000, (1, -2, -5, -1, -10), False, [], 0x5EED0005),

@@ -1560,8 +1560,9 @@ def test_two_pass_tracebacks(al, case, walk_kernel, monkeypatch):
 
 
 @pytest.mark.parametrize("case", [
-    # mode, jump state, l1, l2, pairs, scoring, sites, alphabet, AT_CK_CAP_MB: what it reaches
-    ("local", False, 150, 150, 20000, (2, -2, -5, -2, -10), [], "ACGT", 1100),          # a batch in pieces (the checkpoints of ~8 000 pairs fit the cap)
+    # mode, jump state, l1, l2, pairs, scoring, sites, alphabet, AT_CK_PIECE_PAIRS: what it reaches
+    ("local", False, 150, 150, 20000, (2, -2, -5, -2, -10), [], "ACGT", 6000),          # a batch in pieces (as when its checkpoints exceed AT_CK_CAP_MB)
+    ("global", False, 1000, 1024, 700, (1, -1, -4, -1, -10), [], "ACGT", 256),          # ... on the 64-lane group (teams of walker lanes)
     ("local", False, 150, 150, 33408, (2, -2, -5, -2, -10), [], "ACGT", 0),             # a sliver of 640 pairs on two 32-lane groups x 5 rows, walked by the first wavefronts
     ("fit", True, 150, 500, 33088, (2, -2, -5, -1, -10), [100, 200, 300, 400], "ACGT", 0),   # ... with the jump state
     ("global", False, 150, 150, 701, (1, -1, -1, -1, -10), [], "ACGTN", 0),             # byte words (reads with N): the _b8 kernels; an odd batch
@@ -1598,7 +1599,7 @@ def test_two_pass_walk_kernel_batches(al, case, monkeypatch):
     monkeypatch.setenv("AT_TWO_PASS", "2")
     monkeypatch.setenv("AT_TP_SPLIT", "1")
     if cap:
-        monkeypatch.setenv("AT_CK_CAP_MB", str(cap))
+        monkeypatch.setenv("AT_CK_PIECE_PAIRS", str(cap))
     two = al.align_batch(mode, pairs, traceback=True, render=False)
     cfg = al.last_config
     assert "walk kernel" in cfg, cfg
@@ -1622,8 +1623,9 @@ def test_two_pass_walk_kernel_batches(al, case, monkeypatch):
 
 
 def test_two_pass_default_routing(al, monkeypatch):
-    """By default the two-pass kernels take the shapes on which they win (one strip of 64 lanes x 16 rows: reads of 609 .. 1 024
-    bases; pass 2 there is the walk kernel with teams of lanes) and leave the others to the one-pass kernels."""
+    """By default the two-pass kernels take the shapes on which they win -- one strip of 64 lanes x 16 rows (reads of 609 .. 1 024
+    bases; pass 2 there is the walk kernel with teams of lanes), and fit of 129 .. 152-base reads against a second sequence at least
+    twice as long (the walk kernel, one walker per half-lane) -- and leave the others to the one-pass kernels."""
     rng = random.Random(5)
     monkeypatch.delenv("AT_TWO_PASS", raising=False)
     monkeypatch.delenv("AT_TP_SPLIT", raising=False)
@@ -1635,6 +1637,15 @@ def test_two_pass_default_routing(al, monkeypatch):
         assert ("two-pass" in al.last_config) == want and ("walk kernel" in al.last_config) == want, (l1, al.last_config)
         al.align_batch("global", pairs, traceback=False, render=False)
         assert "two-pass" not in al.last_config
+    for mode, uj, l1, l2, want in (("fit", True, 150, 500, True), ("fit", False, 140, 300, True), ("fit", True, 150, 200, False),
+                                   ("local", False, 150, 500, False), ("fit", False, 120, 500, False)):
+        al.set_scoring(2, -2, -5, -1, -10, uj, [100, 150] if uj else [])
+        pairs = [("".join(rng.choice("ACGT") for _ in range(l1)), "".join(rng.choice("ACGT") for _ in range(l2))) for _ in range(80)]
+        res = al.align_batch(mode, pairs, traceback=True, render=False)
+        assert ("walk kernel" in al.last_config) == want, (mode, uj, l1, l2, al.last_config)
+        for k in (0, 41, 79):
+            r = O.align(O.MODE_NAMES[mode], pairs[k][0], pairs[k][1], 2, -2, -5, -1, -10, uj, [100, 150] if uj else [])
+            assert (int(res["score"][k]), res["ops"][k]) == (r["score"], r["ops"]), (mode, l1, l2, k)
 
 
 @pytest.mark.parametrize("shape", [(1000, 1000, 260), (300, 1000, 300), (150, 160, 500), (40, 64, 400), (500, 512, 200)])

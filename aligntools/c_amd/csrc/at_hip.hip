@@ -559,7 +559,7 @@ static TpLayout tp_layout(const Layout16 &L, int kmode, int l2, bool split = fal
 	t.brow_words = (T + cb + 2) * es;
 	t.off_brow = (int)w; if (!split) w = up4(w + (T + cb + 2) * es);
 	t.off_rck = (int)w; w = up4(w + 64 * es + (T / cb + 3) * 64 * cb * es);   /* (ck_rck_word: the border entries, then tiles of steps) */
-	t.off_cck = (int)w; w = up4(w + (T / cb + 3) * ((nq + 3) / 4 * 4) * 256);   /* (ck_cck_word: chunks in groups of up to 4) */
+	t.off_cck = (int)w; w = up4(w + (T / cb + 3) * ((nq + AT_CK_COL_QUAD - 1) / AT_CK_COL_QUAD * AT_CK_COL_QUAD) * 256);   /* (ck_cck_word: chunks in groups of AT_CK_COL_QUAD) */
 	t.off_rptr = (int)w; if (!split) w = up4(w + (cb / 4) * ((L.k + 3) / 4) * 256);   /* [4 steps][4 rows][lane][row in group] */
 	t.off_rjpl = (int)w; if (!split) w = up4(w + (cb / 4) * ((kg + 3) / 4) * 256);
 	t.words = split ? (w + 63) & ~63LL : w;
@@ -1064,7 +1064,7 @@ static int align_device(at_handle *h, int mode, int64_t npairs,
 		HIP_TRY(h, hipGetLastError());
 		if (tp_split && !env_ll("AT_DIAG_NO_WALK_KERNEL", 0)) {   /* (1: throw-away runs without pass 2 -- what does the sweep alone reach?  Every pair reports garbage ops) */
 			/* the 64-lane groups: teams of lanes per pair of alignments (walk16_team_wave; AT_WALK_TEAMS=0: one walker per half-lane there too) */
-			const bool teams = P.g == 64 && env_ll("AT_WALK_TEAMS", 1) && at_pick_walk16(kmode, P.g, P.k, ts, bits, 1);
+			const bool teams = env_ll("AT_WALK_TEAMS", P.g == 64 ? 1 : 0) && at_pick_walk16(kmode, P.g, P.k, ts, bits, 1);
 			at_walk16_fn wf = at_pick_walk16(kmode, P.g, P.k, ts, bits, teams);
 			if (!wf) return fail(h, AT_ERR_RANGE, "no walk kernel for %d-lane groups x %d rows", P.g, P.k);
 			const size_t lds = std::max(walk_lds(P, true), tail_ok ? walk_lds(PT, true) : 0);
@@ -1076,8 +1076,9 @@ static int align_device(at_handle *h, int mode, int64_t npairs,
 			const long long wcap = env_ll("AT_WALK_WAVES_PER_CU", 0);
 			const long long wmain = std::max<long long>(1, wcap > 0 ? std::min<long long>((nm + 127) / 128, wcap * h->ncu) : (nm + 127) / 128);
 			HIP_TRY(h, hipMemsetAsync(h->d_queue + 8, 0, 16, stream));
-			const long long wteams = ((nm + 1) / 2 + 64 / at_walk16_team_lanes() - 1) / (64 / at_walk16_team_lanes());
-			hipLaunchKernelGGL(wf, dim3((unsigned)(teams ? wteams : wmain + (n_tail + 127) / 128)), dim3(64), lds, stream, b, bt);
+			const int tpw = 64 / at_walk16_team_lanes(P.g);   /* teams per wavefront */
+			const long long wteams = ((nm + 1) / 2 + tpw - 1) / tpw;
+			hipLaunchKernelGGL(wf, dim3((unsigned)((teams ? wteams : wmain) + (n_tail + 127) / 128)), dim3(64), lds, stream, b, bt);
 			HIP_TRY(h, hipGetLastError());
 		}
 		if (n_tail > 0)

@@ -17,7 +17,7 @@
 	at_sweep16_fn at_pick16_ragovl_b##b(int k, int store);                           \
 	at_sweep16_fn at_pick16_tp8_b##b(int kmode, int k, int split);                             \
 	at_sweep16_fn at_pick16_tp64_b##b(int kmode, int k, int ts, int split);                  \
-	at_walk16_fn at_pick_walk16_g8_b##b(int kmode, int g, int k);                    \
+	at_walk16_fn at_pick_walk16_g8_b##b(int kmode, int g, int k, bool teams);                    \
 	at_walk16_fn at_pick_walk16_g64_b##b(int kmode, int k, int ts, bool teams);
 AT_DECL(2)
 AT_DECL(8)
@@ -56,11 +56,11 @@ at_sweep16_fn at_pick16_tp(int kmode, int g, int k, int ts, int bits, int split)
 	return nullptr;
 }
 int at_walk16_team_lanes_b2();
-int at_walk16_team_lanes() { return at_walk16_team_lanes_b2(); }
+int at_walk16_team_lanes8_b2();
+int at_walk16_team_lanes(int g) { return g == 64 ? at_walk16_team_lanes_b2() : at_walk16_team_lanes8_b2(); }
 at_walk16_fn at_pick_walk16(int kmode, int g, int k, int ts, int bits, int teams)
 {
 	if (g == 64) return bits == 8 ? at_pick_walk16_g64_b8(kmode, k, ts, teams != 0) : at_pick_walk16_g64_b2(kmode, k, ts, teams != 0);
-	if (teams) return nullptr;
 	if (ts != 4) return nullptr;
-	return bits == 8 ? at_pick_walk16_g8_b8(kmode, g, k) : at_pick_walk16_g8_b2(kmode, g, k);
+	return bits == 8 ? at_pick_walk16_g8_b8(kmode, g, k, teams != 0) : at_pick_walk16_g8_b2(kmode, g, k, teams != 0);
 }

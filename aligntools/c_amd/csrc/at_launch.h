@@ -18,7 +18,7 @@ at_sweep16_fn at_pick16(int kmode, int g, int k, int ts, int store, bool tb, int
 at_sweep16_fn at_pick16_tp(int kmode, int g, int k, int ts, int bits, int split = 0);   /* two-pass tracebacks (CK kernels; split = 1: pass 2 is a kernel of its own), or nullptr */
 typedef void (*at_walk16_fn)(const at::Sweep16Args, const at::Sweep16Args);   /* (launch, its sliver) */
 at_walk16_fn at_pick_walk16(int kmode, int g, int k, int ts, int bits, int teams = 0);   /* their pass 2 as a kernel of its own (at_walk16.hip.h; teams: several lanes per pair of alignments -- the 64-lane groups), or nullptr */
-int at_walk16_team_lanes();
+int at_walk16_team_lanes(int g);
 /* every packed translation unit is compiled twice: -DAT_BITS16=2 (16 codes per sequence word, score LUT) and
  * -DAT_BITS16=8 (4 bytes per word, compare); its entry points carry the suffix _b2 / _b8 */
 #ifndef AT_BITS16

@@ -1176,9 +1176,10 @@ AT_DEV long long sweep16_items(const Sweep16Args &a, long long wnext, const long
 					Ad = Aup;
 					if constexpr (TP) {
 						/* row checkpoint entry t + 1: my last row after this step (a step outside the matrix repeats the entry before) */
-						static_assert(!TP || AT_CK_ROW_TILE <= 1 || BLK % AT_CK_ROW_TILE == 0, "a tile of row checkpoints lies in one block of steps");
+						static_assert(!TP || AT_CK_ROW_TILE <= 1 || BLK % AT_CK_ROW_TILE == 0 || AT_CK_ROW_TILE % BLK == 0, "a tile of row checkpoints and a block of steps: one holds the other");
 						constexpr int RT = AT_CK_ROW_TILE > 1 ? AT_CK_ROW_TILE : 1;
-						constexpr int so = (k / RT) * 64 * RT * ES + (k % RT) * ck_rck_step<ES>();   /* (t0 is a multiple of the tile: step k lies k / RT tiles on) */
+						/* (ck_p: the entry of step t0.  Tiles of up to BLK steps: step k lies k / RT tiles on; longer tiles hold the whole block of steps) */
+						constexpr int so = RT >= BLK ? k * ES : (k / RT) * 64 * RT * ES + (k % RT) * ck_rck_step<ES>();
 						*(uint2 *)(gs + ck_p + so) = ck_entry<HASJ>(ckL, ckM, ckU, ckJ, e2, o2, cRTagL, cRTagM, cRTagU);
 					}
 					if constexpr (TB) {

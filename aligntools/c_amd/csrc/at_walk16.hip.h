@@ -633,15 +633,15 @@ __global__ __launch_bounds__(64, 2) void at_walk16(const Sweep16Args a, const Sw
 	if (a.only_if && __builtin_amdgcn_readfirstlane(*a.only_if) != a.only_val) return;
 	/* a few wavefronts, each a long chain of dependent steps, beside the sweeps of the launches around them: they go first at the issue */
 	if (AT_WALK_KPRIO) __builtin_amdgcn_s_setprio(AT_WALK_KPRIO);
-	if constexpr (NT > 1) {   /* teams of NT lanes per pair of alignments: one wavefront per 64 / NT pairs */
-		walk16_team_wave<MODE, G, K, TS, BITS, CB, NT>(a, blockIdx.x);
-		return;
-	}
 	long long wave = blockIdx.x, nmain = gridDim.x;
 	if constexpr (G2 > 0) {
 		const long long nt = (t.npairs + 127) / 128;
 		if (wave < nt) { walk16_wave<MODE, G2, K2, TS, BITS, ck_steps(G2)>(t, wave, nullptr, 0); return; }
 		wave -= nt; nmain -= nt;
+	}
+	if constexpr (NT > 1) {   /* teams of NT lanes per pair of alignments: one wavefront per 64 / NT pairs */
+		walk16_team_wave<MODE, G, K, TS, BITS, CB, NT>(a, wave);
+		return;
 	}
 	/* the launch's main units: 64 per wavefront to begin with, the others from the counter behind the sweep's (zeroed by the host) */
 	walk16_wave<MODE, G, K, TS, BITS, CB>(a, wave, a.queue + 8, nmain * 64);   /* (queue[8], [9]: zeroed by the host) */

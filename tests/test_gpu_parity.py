@@ -1568,6 +1568,8 @@ def test_two_pass_tracebacks(al, case, walk_kernel, monkeypatch):
     ("global", False, 150, 150, 701, (1, -1, -1, -1, -10), [], "ACGTN", 0),             # byte words (reads with N): the _b8 kernels; an odd batch
     ("local", False, 1000, 1024, 257, (1, -1, -1, -1, -10), [], "ACGTN", 0),            # ... on the 64-lane group; the last lane holds one alignment
     ("global", False, 150, 150, 1, (2, -2, -5, -2, -10), [], "ACGT", 0),                # one alignment
+    ("local", False, 150, 150, 33408, (2, -2, -5, -2, -10), [], "ACGT", -2),            # AT_WALK_TEAMS=1: teams of 2 lanes on the 8-lane groups, with a sliver
+    ("fit", True, 150, 500, 3001, (2, -2, -5, -1, -10), [100, 200, 300, 400], "ACGT", -2),   # ... the jump state, an odd batch
 ])
 def test_two_pass_walk_kernel_batches(al, case, monkeypatch):
     """Pass 2 as a kernel of its own (AT_TP_SPLIT=1, at_walk16.hip.h): batches cut into pieces by the checkpoint cap, batches that end with
@@ -1598,12 +1600,14 @@ def test_two_pass_walk_kernel_batches(al, case, monkeypatch):
     monkeypatch.setenv("AT_HOST_CHUNKS", "1")
     monkeypatch.setenv("AT_TWO_PASS", "2")
     monkeypatch.setenv("AT_TP_SPLIT", "1")
-    if cap:
+    if cap > 0:
         monkeypatch.setenv("AT_CK_PIECE_PAIRS", str(cap))
+    if cap == -2:
+        monkeypatch.setenv("AT_WALK_TEAMS", "1")
     two = al.align_batch(mode, pairs, traceback=True, render=False)
     cfg = al.last_config
     assert "walk kernel" in cfg, cfg
-    if cap:
+    if cap > 0:
         assert "in pieces of" in cfg, cfg
     if n > 33000:
         assert "as 32-lane items" in cfg, cfg

@@ -954,7 +954,7 @@ static int align_device(at_handle *h, int mode, int64_t npairs,
 		};
 		auto walk_lds = [&](const Layout16 &L, bool ptr_in_lds) -> size_t {
 			const int cb = at::ck_steps(L.g), nsm = kmode == at::K_FITJ ? L.nsm : 0;
-			return (size_t)((nsm + 1) / 2 * 2 + (cb + 1) * 128 + (ptr_in_lds ? 64 * walk_lane_words(L) : 0)) * 4;
+			return (size_t)((nsm + 1) / 2 * 2 + (L.k > 16 ? 0 : (cb + 1) * 128) + (ptr_in_lds ? 64 * walk_lane_words(L) : 0)) * 4;   /* (walk16_lds_words) */
 		};
 		std::string cfg_first;
 		for (int64_t first = 0; first < npairs; first += piece) {

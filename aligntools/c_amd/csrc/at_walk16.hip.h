@@ -36,10 +36,11 @@ namespace at {
 
 /* LDS words of the kernel: the site mask (fit -s), the staging area of the rows above the blocks ((CB + 1) steps x 64 lanes x 2 words),
  * every lane's pointer words (K rows x CB / 4 words [+ the jump plane's]) as [word][lane] */
+template <int K> constexpr bool walk16_no_staging() { return K > 16; }   /* (replay16_lane: phases of 4 steps) */
 template <int MODE, int K, int CB>
 constexpr int walk16_lane_words() { return K * (CB / 4) + (MODE == K_FITJ ? (K + 3) / 4 * (CB / 4) : 0); }
 template <int MODE, int K, int CB>
-constexpr int walk16_lds_words(int nsm) { return ((MODE == K_FITJ ? nsm : 0) + 1) / 2 * 2 + (CB + 1) * 128 + 64 * walk16_lane_words<MODE, K, CB>(); }
+constexpr int walk16_lds_words(int nsm) { return ((MODE == K_FITJ ? nsm : 0) + 1) / 2 * 2 + (walk16_no_staging<K>() ? 0 : (CB + 1) * 128) + 64 * walk16_lane_words<MODE, K, CB>(); }
 
 /* This lane's two blocks -- (blA, cA) of the alignment in the low halves, (blB, cB) of the one in the high halves; band = lane-in-group
  * of the forward sweep, c = t-block -- swept with tags from their checkpoints in the item's region `gi` (lanes lane0 .. of it), pointer
@@ -93,6 +94,11 @@ AT_DEV void replay16_lane(const Sweep16Args &a, const uint32_t *giA, const uint3
 	 *      chain of dependent round trips beside the sweeps of other launches, whose stores fill the memory pipes). ---- */
 	const int stg = S0 + lane * 2;
 	constexpr int PH = K > 16 ? 4 : 8;   /* (19 rows per lane: the registers hold a phase of 4 steps) */
+	/* phases of 4 steps = the 4 steps of one pass of the step loop: the entries go from the registers they arrive in straight into the
+	 * steps that read them, a pass later -- no staging area in LDS (8.7 KB of a wavefront's 28: five wavefronts of walkers per CU become
+	 * eight, 2 048 on the chip; C2's 1 564 team wavefronts were two batches of 1 024) */
+	constexpr bool NOSTG = walk16_no_staging<K>();
+	static_assert(!NOSTG || PH == 4, "entries without staging: a phase per pass of the step loop");
 	static_assert(CB % PH == 0 && PH % 4 == 0, "phases of whole pointer words");
 	static_assert(ES == 2, "row checkpoint entries: (X', L of the row below), ck_entry");
 	typedef uint2 ent_t;
@@ -151,16 +157,19 @@ AT_DEV void replay16_lane(const Sweep16Args &a, const uint32_t *giA, const uint3
 		uint32_t qwa[NWQ0], qwb[NWQ0];
 #pragma unroll
 		for (int x = 0; x < NWQ0; ++x) { qwa[x] = qA[imin(wqa0 + x, lwq0)]; qwb[x] = qB[imin(wqb0 + x, lwq0)]; }
-		stage1(seedA, seedB, 0);
-		stage(1);
+		if constexpr (!NOSTG) {
+			stage1(seedA, seedB, 0);
+			stage(1);
+		}
 		if (AT_TP_STATS == 2) { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); const long long n = (long long)__builtin_amdgcn_s_memtime(); stt[0] += n - stt0; stt0 = n; }
-		if constexpr (CB > PH) ask(1 + PH);
+		if constexpr (!NOSTG && CB > PH) ask(1 + PH);
 		if constexpr (BITS == 2) {
 			const int sha = (jA0 & 15) * 2, shb = (jB0 & 15) * 2;
 #pragma unroll
 			for (int x = 0; x < NW2; ++x) { winA[x] = __builtin_amdgcn_alignbit(ta[x + 1], ta[x], sha); winB[x] = __builtin_amdgcn_alignbit(tb[x + 1], tb[x], shb); }
 		} else { winA[0] = 0; winB[0] = 0; }
-		{
+		if constexpr (NOSTG) { Ad = lohi(seedA.x, seedB.x); lraw0 = lohi(seedA.y, seedB.y); }
+		else {
 			const uint2 e0 = *reinterpret_cast<const uint2 *>(&at_lds[stg]);
 			Ad = e0.x; lraw0 = e0.y;
 		}
@@ -222,7 +231,7 @@ AT_DEV void replay16_lane(const Sweep16Args &a, const uint32_t *giA, const uint3
 
 	if (AT_TP_STATS == 2) { const long long n = (long long)__builtin_amdgcn_s_memtime(); stt[1] += n - stt0; stt0 = n; }
 	for (int s4 = 0; s4 < CB / 4; ++s4) {
-		if constexpr (CB > PH) {
+		if constexpr (!NOSTG && CB > PH) {
 			/* a phase begins (not the first): its entries have arrived -- stage them, ask for the next phase's */
 			if (s4 > 0 && s4 % (PH / 4) == 0) {
 				stage(1 + 4 * s4);
@@ -250,9 +259,18 @@ AT_DEV void replay16_lane(const Sweep16Args &a, const uint32_t *giA, const uint3
 			smA = __builtin_amdgcn_alignbit(at_lds[SM0 + (eA >> 5) + 1], at_lds[SM0 + (eA >> 5)], eA & 31);
 			smB = __builtin_amdgcn_alignbit(at_lds[SM0 + (eB >> 5) + 1], at_lds[SM0 + (eB >> 5)], eB & 31);
 		}
-		uint2 eup4[4];                     /* (the four reads together: one LDS latency per four steps instead of one per step) */
+		uint2 eup4[4];                     /* the row above in this pass's four columns */
+		if constexpr (NOSTG) {
+			/* (asked for a pass ago; the next pass's are asked for now -- a pass behind the last one: entries nobody reads, inside the slack
+			 * the sweep's layout leaves behind a lane's last step) */
 #pragma unroll
-		for (int k = 0; k < 4; ++k) eup4[k] = *reinterpret_cast<const uint2 *>(&at_lds[stg + (1 + 4 * s4 + k) * 128]);
+			for (int k = 0; k < 4; ++k) eup4[k] = make_uint2(lohi(ra[k].x, rb[k].x), lohi(ra[k].y, rb[k].y));
+			if (s4 + 1 < CB / 4) ask(1 + 4 * (s4 + 1));
+		} else {
+			/* (the four reads together: one LDS latency per four steps instead of one per step) */
+#pragma unroll
+			for (int k = 0; k < 4; ++k) eup4[k] = *reinterpret_cast<const uint2 *>(&at_lds[stg + (1 + 4 * s4 + k) * 128]);
+		}
 		auto step = [&](auto KC) {
 			constexpr int k = decltype(KC)::value;
 			constexpr uint32_t SELK = (uint32_t)k * 0x00000101u + (uint32_t)(4 + k) * 0x01010000u;
@@ -417,7 +435,7 @@ AT_DEV void walk16_wave(const Sweep16Args &a, const long long wave, unsigned lon
 	static_assert(CB == ck_steps(G), "the block the forward sweep of this group width checkpoints");
 	const int lane = threadIdx.x;
 	const int nsm = HASJ ? a.nsm : 0;
-	const int SM0 = 0, S0 = (nsm + 1) / 2 * 2, P0 = S0 + (CB + 1) * 128, PJ0 = P0 + K * S4N * 64;
+	const int SM0 = 0, S0 = (nsm + 1) / 2 * 2, P0 = S0 + (walk16_no_staging<K>() ? 0 : (CB + 1) * 128), PJ0 = P0 + K * S4N * 64;
 	(void)KG;
 	long long stt[3] = {0, 0, 0};
 	long long st_t0 = 0, st_t1 = 0, st_rep = 0, st_walk = 0;   /* (-DAT_TP_STATS=1: cycles of this wavefront's start-up, replays and walks) */
@@ -544,7 +562,7 @@ AT_DEV void walk16_team_wave(const Sweep16Args &a, const long long wave)
 	static_assert(NT >= 2 && NT <= 32 && 64 % NT == 0, "team width");
 	const int lane = threadIdx.x, tl = lane % NT, t0 = lane - tl;      /* my place in my team, my team's lane 0 */
 	const int nsm = HASJ ? a.nsm : 0;
-	const int SM0 = 0, S0 = (nsm + 1) / 2 * 2, P0 = S0 + (CB + 1) * 128, PJ0 = P0 + K * S4N * 64;
+	const int SM0 = 0, S0 = (nsm + 1) / 2 * 2, P0 = S0 + (walk16_no_staging<K>() ? 0 : (CB + 1) * 128), PJ0 = P0 + K * S4N * 64;
 	(void)KG; (void)LCB;
 	if constexpr (HASJ) {
 		for (int w = lane; w < nsm; w += 64) at_lds[SM0 + w] = a.sitemask[w];

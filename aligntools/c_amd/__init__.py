@@ -129,7 +129,7 @@ def load_library():
 
 
 def kernel_source_sha16():
-    """Fingerprint of the SWEEP kernels' sources -- at_sweep.hip.h, at_sweep16.hip.h, at_myers.hip.h, at_launch.h and the instantiation
+    """Fingerprint of the SWEEP kernels' sources -- at_sweep.hip.h, at_sweep16.hip.h, at_walk16.hip.h, at_myers.hip.h, at_launch.h and the instantiation
     units at_k*.hip / at_myers.hip; not the packing / rendering kernels nor the host-side plumbing (at_hip.hip, at_comm.hip), whose
     choices show in the kernel configuration string: the committed PMC counters under profiles/ belong to one state of those
     kernels, and bench.py prices its roofline with them only while this fingerprint still matches."""
@@ -137,7 +137,7 @@ def kernel_source_sha16():
     d = os.path.join(HERE, "csrc")
     h = hashlib.sha256()
     for name in sorted(os.listdir(d)):
-        if name in ("at_sweep.hip.h", "at_sweep16.hip.h", "at_myers.hip.h", "at_launch.h", "at_myers.hip") or (name.startswith("at_k") and name.endswith(".hip")):
+        if name in ("at_sweep.hip.h", "at_sweep16.hip.h", "at_walk16.hip.h", "at_myers.hip.h", "at_launch.h", "at_myers.hip") or (name.startswith("at_k") and name.endswith(".hip")):
             h.update(name.encode() + b"\0")
             h.update(open(os.path.join(d, name), "rb").read())
     return h.hexdigest()[:16]

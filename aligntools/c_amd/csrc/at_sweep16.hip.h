@@ -227,11 +227,13 @@ AT_DEV int pidx(int wr, int r, int lane, int NL)
  * Two-pass tracebacks (round 4; CK kernels).
  *
  * The forward sweep of a CK kernel is the scores-only sweep (no priority tags, no pointer words: a third of the
- * instructions of a row-step less) plus CHECKPOINTS in the wave's global slot:
- *   row checkpoints     every lane, every step: (L, M, U[, J]) of its LAST row, both alignments packed -- what the lane
- *                       below needs of the row above it.  Entry e = t + 1 is the state after step t, entry 0 the border.
+ * instructions of a row-step less) plus CHECKPOINTS -- in the wave's global slot, or (SPLIT: pass 2 is the walk kernel of
+ * at_walk16.hip.h, the default wherever two-pass tracebacks are the default) in the work item's region of a per-launch buffer:
+ *   row checkpoints     every lane, every step: its LAST row as the lane below sees it (ck_entry: X' = max(L, M, U[, J]) with
+ *                       the winner's tag, L of the row below), both alignments packed, 8 bytes.  Entry e = t + 1 is the state
+ *                       after step t, entry 0 the border.
  *   column checkpoints  every lane, every CB steps: (M + o, U[, J]) of its K rows -- what a lane needs of its own past.
- * The traceback then runs in ROUNDS.  A block is (lane band, CB steps of that lane): K rows x CB columns.  In a round
+ * (Layout: ck_rck_word / ck_cck_word.)  Without the walk kernel the traceback then runs in ROUNDS inside this kernel.  A block is (lane band, CB steps of that lane): K rows x CB columns.  In a round
  * every lane replays two blocks, one per 16-bit half, each for the alignment of that half of its group, on its own:
  * the cell above comes from the row checkpoint instead of a DPP move, so nothing ties the lanes (or the halves)
  * together and G lanes give every alignment G blocks per round -- laid out along the direction its walk is taking
@@ -241,8 +243,8 @@ AT_DEV int pidx(int wr, int r, int lane, int NL)
  * one-pass kernels (trace_back_gla / _local_affine / _fit_affine_jump, alignment.h:372-412, 558-592, 766-800).
  *
  * A round, in order: (1) every walker's anchor goes to the lanes of its group (shuffles), each lane works out its two
- * blocks; (2) replay16_block: the CB + 1 row-checkpoint entries above the block are loaded together and staged in LDS as
- * the lane below sees them (tagged X', L of the row below), the state at the block's first step is rebuilt from the column
+ * blocks; (2) replay16_block: the CB + 1 row-checkpoint entries above the block are loaded together and staged in LDS
+ * (the halves of the lane's two blocks joined), the state at the block's first step is rebuilt from the column
  * checkpoint (or the border), CB steps are swept, the pointer words stored; (3) the walks, in PHASES: every walker names
  * the block it stands in, the wave copies those blocks from the slot into LDS together (one round trip), every walker
  * walks its block -- four cells ahead along its direction per look, the state machine in bit arithmetic -- until it
@@ -250,8 +252,9 @@ AT_DEV int pidx(int wr, int r, int lane, int NL)
  *
  * What it buys (one MI355X, profiles/r04/two_pass_ab.jsonl): the 64-lane group with 16 rows per lane -- reads of 609 .. 1 024
  * bases, where the one-pass kernels hold 4 rows per lane in four strips -- C3 2 940 -> 3 170 GCUPS with launches in flight,
- * 2 110 -> 2 860 one launch at a time.  (Since pass 2 exists as a kernel of its own -- at_walk16.hip.h, teams of walker lanes: 4 050 /
- * 3 160 -- that form is the default there and the rounds below are what AT_TP_SPLIT=0 and a failed allocation fall back to.)  The 8-lane groups x 19 rows lose (C2 3 050 -> 2 850, C4 2 200 ->
+ * 2 110 -> 2 860 one launch at a time.  (Since pass 2 exists as a kernel of its own -- at_walk16.hip.h, teams of walker lanes: 4 360 -
+ * 4 530 / 3 290 -- that form is the default there and the rounds below are what AT_TP_SPLIT=0 and a failed allocation fall back
+ * to.)  The 8-lane groups x 19 rows lose (C2 3 050 -> 2 850, C4 2 200 ->
  * 1 580: a round replays 19 x 16 cells in every lane for the dozen cells a short walk needs, and long walks need ten rounds)
  * and stay on the one-pass kernels unless AT_TWO_PASS=2 asks.
  * ====================================================================================================================== */

@@ -19,11 +19,13 @@
  * halves: half 0 of a lane walks even alignments, half 1 odd ones, and `lohi` joins two unrelated blocks exactly as the
  * sweep packed them.
  *
- * Two forms.  walk16_wave (the 8-lane groups; AT_TP_SPLIT=1): every half-lane a walker of its own, persistent wavefronts
- * that refill finished halves from two counters.  walk16_team_wave (the 64-lane groups, where a walk crosses a hundred
- * blocks; the default there): teams of NT lanes share one pair of alignments, a round replays the NT blocks per alignment
- * the walk is heading for, and the chain of dependent rounds per alignment is a third as long (C3: 2 900 -> 4 050 GCUPS with
- * launches in flight, 2 660 -> 3 160 one at a time, against the rounds inside the sweep's kernel).  DESIGN.md 3.6.1.
+ * Two forms.  walk16_wave (the 8-lane groups: the default for fit against a long second sequence -- C4 2 200 -> 2 390 - 2 480
+ * GCUPS --, AT_TWO_PASS=2 AT_TP_SPLIT=1 elsewhere): every half-lane a walker of its own, a wavefront per 128 alignments
+ * (AT_WALK_WAVES_PER_CU: persistent wavefronts that refill finished halves from two counters).  walk16_team_wave (the
+ * 64-lane groups, where a walk crosses a hundred blocks; the default there): teams of NT lanes share one pair of
+ * alignments, a round replays the NT blocks per alignment the walk is heading for, and the chain of dependent rounds per
+ * alignment is a third as long (C3: 2 940 -> 4 360 - 4 530 GCUPS with launches in flight, 2 090 -> 3 290 one at a time,
+ * against the one-pass kernels).  DESIGN.md 3.6.1.
  */
 #pragma once
 #include "at_sweep16.hip.h"

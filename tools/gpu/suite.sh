@@ -26,6 +26,7 @@ for seed in ${AT_FUZZ_SEEDS:-4301 4302 4303 4304}; do
   AT_TWO_PASS=2 timeout -k 10 900 python3 tests/fuzz_parity.py $N $((seed + 50)) >> $O/fuzz_parity.txt 2>&1 || { tail -30 $O/fuzz_parity.txt; exit 1; }
 done
 AT_TWO_PASS=2 AT_TP_SPLIT=1 AT_FUZZ_TB=1 timeout -k 10 900 python3 tests/fuzz_parity.py $N 5101 >> $O/fuzz_parity.txt 2>&1 || { tail -30 $O/fuzz_parity.txt; exit 1; }   # pass 2 as a kernel of its own
+timeout -k 10 600 python3 tests/fuzz_walk_kernel.py 1500 6102 > $O/fuzz_walk_kernel.txt 2>&1 || { tail -30 $O/fuzz_walk_kernel.txt; exit 1; }   # ... aimed at its shape classes
 AT_FUZZ_MODES=fitj,overlap timeout -k 10 900 python3 tests/fuzz_parity.py $N 4401 >> $O/fuzz_parity.txt 2>&1 || { tail -30 $O/fuzz_parity.txt; exit 1; }
 AT_FUZZ_MODES=overlap,edit AT_FUZZ_TB=0 timeout -k 10 600 python3 tests/fuzz_parity.py $N 4501 >> $O/fuzz_parity.txt 2>&1 || { tail -30 $O/fuzz_parity.txt; exit 1; }
 AT_FUZZ_MODES=edit AT_FUZZ_EDIT_UNIT=1 AT_MYERS_LANE_MIN_PAIRS=1 timeout -k 10 600 python3 tests/fuzz_parity.py $N 4601 >> $O/fuzz_parity.txt 2>&1 || { tail -30 $O/fuzz_parity.txt; exit 1; }

@@ -44,6 +44,23 @@ def test_fuzz_campaign_aimed(aim):
         assert sum(1 for k in seen if "myers" in k and "64x1" in k) >= 5, sorted(seen)   # (2, 3, 4, 5, 8, 16, 32 words per lane: most of them)
 
 
+def test_fuzz_campaign_walk_kernel():
+    """Round 4's walk kernel (at_walk16.hip.h) gets a campaign drawn inside its shape classes (tests/fuzz_walk_kernel.py): both group
+    widths, teams of lanes on and off, batches in pieces, byte alphabets -- whole batches against the one-pass kernels, samples against
+    the oracle."""
+    import fuzz_walk_kernel
+    saved = {k: os.environ.get(k) for k in ("AT_PACKED_MIN_ROUNDS", "AT_HOST_CHUNKS")}
+    try:
+        n = fuzz_walk_kernel.run(int(os.environ.get("AT_FUZZ_WALK_BATCHES", "120")), 41, verbose=False)
+    finally:
+        for k, v in saved.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
+    assert n >= 120
+
+
 def test_fuzz_campaign_reached_every_kernel_family():
     """(runs behind the four campaigns of this module) what their batches ran on, by at_last_config"""
     if len(SEEN) == 0:

@@ -426,11 +426,13 @@ struct Layout16 {
  * 305..608 bases as 2 groups of 32 lanes (10 .. 19 rows per lane), everything
  * else as one group of 64 lanes.  AT_GROUP = 8 / 16 / 32 / 64 caps the choice (A/B runs); ragged frames name their group width themselves. */
 /* The 8-lane groups x 19 rows (reads of 129 .. 152 bases): which batches take the two-pass kernels with the walk kernel by default --
- * fit (with or without -s) against a second sequence at least twice as long: the sweep is long against the walkers' chain of rounds
+ * fit (with or without -s) against a second sequence at least one and a half times as long: the sweep is long against the walkers' chain
+ * of rounds (150-base reads, launches in flight / one at a time against the one-pass kernels, -s / without: l2 = 160 +12 % / -2 %, +7 % /
+ * -3 %; l2 = 225 +13 % / +4 %, +8 % / +7 %; l2 = 300 +12 % / +10 %, +12 % / +11 %; l2 = 400 +12 % / +14 %, +16 % / +17 %; r05n)
  * (same box, launches in flight / one at a time: C4 150 x 500 -s 2 210 -> 2 380 / 1 960 -> 2 180 GCUPS, the same without -s 3 150 -> 3 750 /
  * 2 590 -> 3 350).  Global and local 150 x 150 gain with launches in flight (2 470 -> 2 700, 3 050 -> 3 180) and lose alone (2 380 ->
  * 2 230, 2 800 -> 2 490): AT_TWO_PASS=2 AT_TP_SPLIT=1 asks for them. */
-static bool tp_split_narrow_default(int kmode, int l1, int l2) { return (kmode == at::K_FITJ || kmode == at::K_FIT) && l2 >= 2 * l1; }
+static bool tp_split_narrow_default(int kmode, int l1, int l2) { return (kmode == at::K_FITJ || kmode == at::K_FIT) && 2LL * l2 >= 3LL * l1; }
 static Layout16 layout16_for(bool tb, bool hasj, int l1, int l2, int ts, int force_g = 0, bool overlap = false, int kmode = -1, int force_k = 0, int two_pass = 0)   /* two_pass: 1 = the rounds inside the sweep's kernel (its staging area and walkers' tiles in LDS), 2 = a walk kernel; force_g: 8 / 16 = ragged frames on that group width; 64 = the 64-lane items behind a batch of narrow-group items, force_k rows per lane */
 {
 	Layout16 L;

@@ -1629,7 +1629,7 @@ def test_two_pass_walk_kernel_batches(al, case, monkeypatch):
 def test_two_pass_default_routing(al, monkeypatch):
     """By default the two-pass kernels take the shapes on which they win -- one strip of 64 lanes x 16 rows (reads of 609 .. 1 024
     bases; pass 2 there is the walk kernel with teams of lanes), and fit of 129 .. 152-base reads against a second sequence at least
-    twice as long (the walk kernel, one walker per half-lane) -- and leave the others to the one-pass kernels."""
+    one and a half times as long (the walk kernel, one walker per half-lane) -- and leave the others to the one-pass kernels."""
     rng = random.Random(5)
     monkeypatch.delenv("AT_TWO_PASS", raising=False)
     monkeypatch.delenv("AT_TP_SPLIT", raising=False)
@@ -1641,7 +1641,7 @@ def test_two_pass_default_routing(al, monkeypatch):
         assert ("two-pass" in al.last_config) == want and ("walk kernel" in al.last_config) == want, (l1, al.last_config)
         al.align_batch("global", pairs, traceback=False, render=False)
         assert "two-pass" not in al.last_config
-    for mode, uj, l1, l2, want in (("fit", True, 150, 500, True), ("fit", False, 140, 300, True), ("fit", True, 150, 200, False),
+    for mode, uj, l1, l2, want in (("fit", True, 150, 500, True), ("fit", False, 140, 300, True), ("fit", True, 150, 200, False), ("fit", True, 150, 226, True),
                                    ("local", False, 150, 500, False), ("fit", False, 120, 500, False)):
         al.set_scoring(2, -2, -5, -1, -10, uj, [100, 150] if uj else [])
         pairs = [("".join(rng.choice("ACGT") for _ in range(l1)), "".join(rng.choice("ACGT") for _ in range(l2))) for _ in range(80)]

@@ -96,3 +96,22 @@ def test_bench_under_the_launcher_gathers_groups_of_steps(world, backend, extra)
     g = d["config"]["gather"]
     assert g["steps_per_collective"] == int(extra[extra.index("--gather-every") + 1]) and g["cigar_bytes_per_rank_and_step"] > 0
     assert g["world"] == world and len(g["ranks"]) == world and g["backend"].startswith("nccl (RCCL" if backend == "nccl" else "gloo")
+
+
+def test_committed_counters_belong_to_todays_kernel_sources():
+    """bench.py prices its roofline with the PMC counters under profiles/<round>/traffic_<W>[_scores].json only while they carry the
+    fingerprint of the sweep kernels' sources (valu_roofline: otherwise achieved / peak / frac are null and `stale` says why).  A
+    kernel edit without a new collection (tools/collect_traffic.py on the GPU box) is caught here, on the CPU, not by a driver bench
+    line without a roofline."""
+    import importlib.util
+    import aligntools.c_amd as A
+    spec = importlib.util.spec_from_file_location("bench_for_test", os.path.join(ROOT, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    sha = A.kernel_source_sha16()
+    for w, tb in (("C2", True), ("C2", False), ("C3", True), ("C4", True), ("C5", True)):
+        prof = bench._traffic(w, tb)
+        assert prof is not None, (w, tb)
+        assert prof.get("kernel_source_sha16") == sha, "profiles/%s/traffic_%s%s.json was collected on other kernel sources (%s, today %s)" % (
+            bench.PROFILE_ROUND, w, "" if tb else "_scores", prof.get("kernel_source_sha16"), sha)
+        assert (prof.get("sq_counters_per_launch") or {}).get("SQ_INSTS_VALU"), (w, tb)
